@@ -1,0 +1,492 @@
+"""CPU oracle: a functional PyTorch-CPU restatement of the reference hot path.
+
+TEST INFRASTRUCTURE ONLY.  Imported by tests/, __graft_entry__.smoke() and bench.py's
+``cpu_baseline`` leg as the *checker*; never by the product package
+(bayesian-enhancement-model_amd/), which has no CPU path and fails loudly without its HIP library.
+
+Every function restates one piece of vfrantc/Bayesian-Enhancement-Model (paths relative to
+/root/reference) and is pinned against golden vectors produced by importing the reference
+itself on CPU (tests/golden/make_golden.py -> tests/golden/*.npz, checked by
+tests/test_oracle_golden.py).  Parity status: PINNED for every function below except
+``cv2_resize_down`` (cv2 is not installed anywhere in this environment; restated from the
+INTER_LINEAR definition, "parity unpinned").
+
+All tensors are float32 NCHW, weights come from a flat ``state_dict``-style mapping
+``sd[prefix + name]`` using the reference's own key names.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+from typing import Dict, Iterable, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+SD = Dict[str, torch.Tensor]
+
+# ----------------------------------------------------------------------------------------------
+# A9  selective scan            basicsr/vmamba/models/csms6s.py:29-72 (selective_scan_torch)
+# ----------------------------------------------------------------------------------------------
+
+def selective_scan_ref(u, delta, A, B, C, D=None, delta_bias=None, delta_softplus=True):
+    """u, delta: (Bt, K*Cd, L); A: (K*Cd, N); B, C: (Bt, K, N, L); D, delta_bias: (K*Cd).
+
+    h_t = exp(dt_t * A) * h_{t-1} + dt_t * B_t * u_t ;  y_t = <C_t, h_t> + D * u_t,
+    dt = softplus(delta + delta_bias).  Time loop kept in the per-step form of csms6s.py:61-66.
+    """
+    Bt, K, N, L = B.shape
+    KC = u.shape[1]
+    Cd = KC // K
+    dt = delta.float()
+    if delta_bias is not None:
+        dt = dt + delta_bias.float()[None, :, None]
+    if delta_softplus:
+        dt = F.softplus(dt)
+    u = u.float()
+    Bx = B.float().repeat_interleave(Cd, dim=1)  # (Bt, KC, N, L): group k serves channels k*Cd..
+    Cx = C.float().repeat_interleave(Cd, dim=1)
+    dA = torch.exp(dt.unsqueeze(2) * A.float()[None, :, :, None])          # (Bt, KC, N, L)
+    dBu = (dt * u).unsqueeze(2) * Bx                                       # (Bt, KC, N, L)
+    h = torch.zeros(Bt, KC, N)
+    ys = []
+    for t in range(L):
+        h = dA[..., t] * h + dBu[..., t]
+        ys.append((h * Cx[..., t]).sum(-1))
+    y = torch.stack(ys, dim=2)
+    if D is not None:
+        y = y + u * D.float()[None, :, None]
+    return y
+
+
+_C_LIB = None
+
+
+def _c_lib():
+    """oracle/_build/liboracle_scan.so (compiled by oracle/Makefile from selective_scan_oracle.c)."""
+    global _C_LIB
+    if _C_LIB is None:
+        here = os.path.dirname(os.path.abspath(__file__))
+        path = os.path.join(here, "_build", "liboracle_scan.so")
+        if not os.path.exists(path):
+            import subprocess
+            subprocess.check_call(["make", "-s", "-C", here])
+        _C_LIB = ctypes.CDLL(path)
+        _C_LIB.oracle_selective_scan_f32.restype = ctypes.c_int
+    return _C_LIB
+
+
+def selective_scan_c(u, delta, A, B, C, D=None, delta_bias=None, delta_softplus=True):
+    """Same contract as selective_scan_ref, evaluated by the plain-C restatement (fast enough for
+    L = 16384).  The C code accumulates the recurrence in float like the reference."""
+    lib = _c_lib()
+    Bt, K, N, L = B.shape
+    KC = u.shape[1]
+    f = lambda t: None if t is None else t.detach().contiguous().float()
+    u_, d_, A_, B_, C_, D_, b_ = map(f, (u, delta, A, B, C, D, delta_bias))
+    out = torch.empty(Bt, KC, L, dtype=torch.float32)
+    p = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())
+    rc = lib.oracle_selective_scan_f32(p(u_), p(d_), p(A_), p(B_), p(C_), p(D_), p(b_), p(out),
+                                       ctypes.c_int(Bt), ctypes.c_int(KC), ctypes.c_int(L),
+                                       ctypes.c_int(N), ctypes.c_int(K), ctypes.c_int(int(delta_softplus)))
+    if rc != 0:
+        raise RuntimeError(f"oracle_selective_scan_f32 rc={rc}")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# A8  cross scan / merge        basicsr/vmamba/models/csm_triton.py:22-85
+# ----------------------------------------------------------------------------------------------
+
+def cross_scan_ref(x):
+    """(B,C,H,W) -> (B,4,C,H*W): row-major, column-major, and both reversed."""
+    B, C, H, W = x.shape
+    row = x.reshape(B, C, H * W)
+    col = x.transpose(2, 3).reshape(B, C, H * W)
+    return torch.stack([row, col, row.flip(-1), col.flip(-1)], dim=1)
+
+
+def cross_merge_ref(ys):
+    """(B,4,C,H,W) (each plane holding a length-H*W sequence) -> (B,C,H*W)."""
+    B, K, C, H, W = ys.shape
+    s = ys.reshape(B, 4, C, H * W)
+    row = s[:, 0] + s[:, 2].flip(-1)
+    col = s[:, 1] + s[:, 3].flip(-1)
+    return row + col.reshape(B, C, W, H).transpose(2, 3).reshape(B, C, H * W)
+
+
+# ----------------------------------------------------------------------------------------------
+# A11 Haar / quaternion         basicsr/QD/model4.py:7-37, basicsr/QD/quaternion.py:3-17
+# ----------------------------------------------------------------------------------------------
+
+def dwt_ref(x):
+    a = x[:, :, 0::2, 0::2] / 2   # even row, even col
+    b = x[:, :, 1::2, 0::2] / 2   # odd row, even col
+    c = x[:, :, 0::2, 1::2] / 2   # even row, odd col
+    d = x[:, :, 1::2, 1::2] / 2
+    return torch.cat([a + b + c + d, -a - b + c + d, -a + b - c + d, a - b - c + d], dim=1)
+
+
+def iwt_ref(x):
+    B, C4, H, W = x.shape
+    C = C4 // 4
+    ll, hl, lh, hh = (x[:, i * C:(i + 1) * C].float() / 2 for i in range(4))
+    out = torch.zeros(B, C, 2 * H, 2 * W, dtype=torch.float32)   # always f32 (model4.py:31)
+    out[:, :, 0::2, 0::2] = ll - hl - lh + hh
+    out[:, :, 1::2, 0::2] = ll - hl + lh - hh
+    out[:, :, 0::2, 1::2] = ll + hl - lh - hh
+    out[:, :, 1::2, 1::2] = ll + hl + lh + hh
+    return out
+
+
+def hamilton_ref(p, q):
+    r1, i1, j1, k1 = p.unbind(1)
+    r2, i2, j2, k2 = q.unbind(1)
+    return torch.stack([
+        r1 * r2 - i1 * i2 - j1 * j2 - k1 * k2,
+        r1 * i2 + i1 * r2 + j1 * k2 - k1 * j2,
+        r1 * j2 - i1 * k2 + j1 * r2 + k1 * i2,
+        r1 * k2 + i1 * j2 - j1 * i2 + k1 * r2], dim=1)
+
+
+# ----------------------------------------------------------------------------------------------
+# A7  VSSBlock pieces           basicsr/vmamba/models/vmamba.py:42-63,116-133,547-716,1319-1334
+# ----------------------------------------------------------------------------------------------
+
+def layernorm2d_ref(x, w, b, eps=1e-5):
+    return F.layer_norm(x.permute(0, 2, 3, 1), (x.shape[1],), w, b, eps).permute(0, 3, 1, 2)
+
+
+def _w4(w):
+    return w if w.dim() == 4 else w[:, :, None, None]
+
+
+class EpsSource:
+    """Bayesian weight sampling (basicsr/bayesian/conv.py:106-114, linear.py:82-90).
+
+    ``eps`` maps '<layer prefix>weight' / '<layer prefix>bias' to the N(0,1) draw used for that
+    layer (recorded from the reference, or freshly drawn); ``None`` means deterministic (mu)."""
+
+    def __init__(self, eps: Optional[Dict[str, torch.Tensor]] = None, generator=None, record=False):
+        self.eps = eps
+        self.gen = generator
+        self.record = {} if record else None
+
+    def draw(self, key, like):
+        if self.eps is not None:
+            return self.eps[key].reshape(like.shape)
+        e = torch.randn(like.shape, generator=self.gen)
+        if self.record is not None:
+            self.record[key] = e
+        return e
+
+
+def _wb(sd: SD, pre: str, src: Optional[EpsSource]):
+    """(weight, bias) of a conv/linear leaf, plain or Bayesian ('mu_weight'/'rho_weight')."""
+    if pre + "weight" in sd:
+        return sd[pre + "weight"], sd.get(pre + "bias")
+    mu_w = sd[pre + "mu_weight"]
+    mu_b = sd.get(pre + "mu_bias")
+    if src is None:
+        return mu_w, mu_b
+    w = mu_w + torch.log1p(torch.exp(sd[pre + "rho_weight"])) * src.draw(pre + "weight", mu_w)
+    b = None
+    if mu_b is not None:
+        b = mu_b + torch.log1p(torch.exp(sd[pre + "rho_bias"])) * src.draw(pre + "bias", mu_b)
+    return w, b
+
+
+def ss2d_core_ref(sd: SD, pre: str, x, scan=selective_scan_ref):
+    """forward_corev2 (vmamba.py:547-698) for forward_type v05_noz: cross-scan, x_proj, dt_proj,
+    selective scan in 4 directions, cross-merge, out_norm."""
+    B, Cd, H, W = x.shape
+    L = H * W
+    xw = sd[pre + "x_proj_weight"]            # (4, R+2N, Cd)
+    dtw = sd[pre + "dt_projs_weight"]         # (4, Cd, R)
+    K, _, R = dtw.shape
+    N = sd[pre + "A_logs"].shape[1]
+    xs = cross_scan_ref(x)                                                    # (B,4,Cd,L)
+    x_dbl = torch.einsum("bkcl,kjc->bkjl", xs, xw)
+    dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)
+    dts = torch.einsum("bkrl,kcr->bkcl", dts, dtw)
+    A = -torch.exp(sd[pre + "A_logs"].float())
+    ys = scan(xs.reshape(B, K * Cd, L), dts.reshape(B, K * Cd, L).contiguous(), A,
+              Bs.contiguous(), Cs.contiguous(), sd[pre + "Ds"].float(),
+              sd[pre + "dt_projs_bias"].reshape(-1).float(), True)
+    y = cross_merge_ref(ys.reshape(B, K, Cd, H, W)).reshape(B, Cd, H, W)
+    return layernorm2d_ref(y, sd[pre + "out_norm.weight"], sd[pre + "out_norm.bias"])
+
+
+def ss2d_ref(sd: SD, pre: str, x, src=None, scan=selective_scan_ref):
+    """SS2D.forwardv2 (vmamba.py:700-716) with disable_z (v05_noz)."""
+    w, b = _wb(sd, pre + "in_proj.", src)
+    x = F.conv2d(x, _w4(w), b)
+    w, b = _wb(sd, pre + "conv2d.", src)
+    x = F.silu(F.conv2d(x, w, b, padding=1, groups=x.shape[1]))
+    y = ss2d_core_ref(sd, pre, x, scan)
+    w, b = _wb(sd, pre + "out_proj.", src)
+    return F.conv2d(y, _w4(w), b)
+
+
+def gdmlp_ref(sd: SD, pre: str, x, src=None):
+    """gdMlp (vmamba.py:116-133)."""
+    w, b = _wb(sd, pre + "project_in.", src)
+    x = F.conv2d(x, w, b)
+    w, b = _wb(sd, pre + "dwconv.", src)
+    x1, x2 = F.conv2d(x, w, b, padding=1, groups=x.shape[1]).chunk(2, dim=1)
+    w, b = _wb(sd, pre + "project_out.", src)
+    return F.conv2d(F.gelu(x1) * x2, w, b)
+
+
+def vssblock_ref(sd: SD, pre: str, x, src=None, scan=selective_scan_ref):
+    """VSSBlock._forwardv01 (vmamba.py:1319-1334), post_norm=False, drop_path=0."""
+    x = x + ss2d_ref(sd, pre + "op.", layernorm2d_ref(x, sd[pre + "norm.weight"], sd[pre + "norm.bias"]), src, scan)
+    x = x + gdmlp_ref(sd, pre + "mlp.", layernorm2d_ref(x, sd[pre + "norm2.weight"], sd[pre + "norm2.bias"]), src)
+    return x
+
+
+def _blocks(sd: SD, pre: str, x, src, scan):
+    i = 0
+    while f"{pre}{i}.norm.weight" in sd:
+        x = vssblock_ref(sd, f"{pre}{i}.", x, src, scan)
+        i += 1
+    assert i > 0, f"no VSSBlocks under {pre}"
+    return x
+
+
+# ----------------------------------------------------------------------------------------------
+# A5  quaternion-Retinex decomposition   basicsr/QD/model4.py:167-262, model1.py,
+#     wavelet-domain variant: basicsr/archs/DecompDualBranchDDWavelet_arch.py:80-132
+# ----------------------------------------------------------------------------------------------
+
+def quaternion_stack_ref(img):
+    """RGB -> (q1_r,q2_r,q1_i,q2_i,q1_j,q2_j,q1_k,q2_k); q1 = RGB/(max_c+1e-7), q2 = RGB."""
+    mx = img.max(dim=1, keepdim=True)[0]
+    q1 = img / (mx + 1e-7)
+    z = torch.zeros_like(mx)
+    return torch.cat([z, z, q1[:, 0:1], img[:, 0:1], q1[:, 1:2], img[:, 1:2], q1[:, 2:3], img[:, 2:3]], dim=1)
+
+
+def cross_attention_ref(sd: SD, pre: str, f1, f2):
+    """SymmetricCrossAttention (model4.py:81-139), heads=1: channel attention, C x C logits over HW."""
+    B, C, H, W = f1.shape
+    pj = lambda n, t: F.conv2d(t, sd[pre + n + ".weight"], sd[pre + n + ".bias"]).reshape(B, C, H * W)
+    scale = C ** -0.5
+    q1, k2, v2 = pj("q1_proj", f1) * scale, pj("k2_proj", f2), pj("v2_proj", f2)
+    q2, k1, v1 = pj("q2_proj", f2) * scale, pj("k1_proj", f1), pj("v1_proj", f1)
+    c1 = (torch.softmax(q1 @ k2.transpose(1, 2), dim=-1) @ v2).reshape(B, C, H, W)
+    c2 = (torch.softmax(q2 @ k1.transpose(1, 2), dim=-1) @ v1).reshape(B, C, H, W)
+    o1 = F.conv2d(c1, sd[pre + "out1.weight"], sd[pre + "out1.bias"]) + f1
+    o2 = F.conv2d(c2, sd[pre + "out2.weight"], sd[pre + "out2.bias"]) + f2
+    return o1, o2
+
+
+def decomp_trunk_ref(sd: SD, pre: str, img):
+    """Shared trunk: quaternion stack -> DWT -> convs -> cross attention -> fuse -> conv_out +
+    sharpening.  Returns the 32-channel wavelet-domain map (before IWT / index split)."""
+    c3 = lambda n, t: F.conv2d(t, sd[pre + n + ".weight"], sd[pre + n + ".bias"], padding=1)
+    feat = c3("conv_in", dwt_ref(quaternion_stack_ref(img)))
+    f1 = c3("branch_q1.2", F.relu(c3("branch_q1.0", feat))) + feat
+    f2 = c3("branch_q2.2", F.relu(c3("branch_q2.0", feat))) + feat
+    f1, f2 = cross_attention_ref(sd, pre + "cross_attn.", f1, f2)
+    fused = F.conv2d(torch.cat([f1, f2], 1), sd[pre + "fuse.weight"], sd[pre + "fuse.bias"])
+    out = c3("conv_out", fused)
+    return out + c3("sharpening", out)
+
+
+def decomp_wavelet_ref(sd: SD, pre: str, img):
+    """MyDecomp.forward (DecompDualBranchDDWavelet_arch.py:80-132): even channels -> Q1_w, odd -> Q2_w."""
+    out = decomp_trunk_ref(sd, pre, img)
+    return out[:, 0::2], out[:, 1::2]
+
+
+def decomp_full_ref(sd: SD, pre: str, img):
+    """Decomp.forward of model1 (no smoothing) / model4 (PostSmooth when smooth_q* weights exist)."""
+    out = iwt_ref(decomp_trunk_ref(sd, pre, img))
+    q1, q2 = out[:, [0, 2, 4, 6]], out[:, [1, 3, 5, 7]]
+    if pre + "smooth_q1.conv.weight" in sd:
+        sm = lambda n, t: t + F.relu(F.conv2d(t, sd[pre + n + ".conv.weight"], sd[pre + n + ".conv.bias"], padding=1, groups=4))
+        q1, q2 = sm("smooth_q1", q1), sm("smooth_q2", q2)
+    return q1, q2
+
+
+# ----------------------------------------------------------------------------------------------
+# A6  Stage-II networks
+# ----------------------------------------------------------------------------------------------
+
+def _levels(sd: SD, pre: str) -> int:
+    n = 0
+    while f"{pre}{n}.weight" in sd:
+        n += 1
+    return n
+
+
+def ddwavelet_ref(sd: SD, x, scan=selective_scan_ref, pre: str = ""):
+    """DecompDualBranchDDWavelet.forward (DecompDualBranchDDWavelet_arch.py:301-369). Returns final_out."""
+    img, cond = x[:, 0:3], x[:, 3:6]
+    q1i, q2i = decomp_wavelet_ref(sd, pre + "decomp.", img)
+    q1c, q2c = decomp_wavelet_ref(sd, pre + "decomp.", cond)
+    nl = _levels(sd, pre + "down_layers_Q1.") + 1
+    feats, skips = {}, {}
+    for br, q in (("Q1", torch.cat([q1i, q1c], 1)), ("Q2", torch.cat([q2i, q2c], 1))):
+        f = F.conv2d(q, sd[f"{pre}first_conv_{br}.weight"], sd[f"{pre}first_conv_{br}.bias"], padding=1)
+        sk = []
+        for i in range(nl - 1):
+            f = _blocks(sd, f"{pre}encoders_{br}.{i}.", f, None, scan)
+            sk.append(f)
+            f = F.conv2d(f, sd[f"{pre}down_layers_{br}.{i}.weight"], None, stride=2, padding=1)
+        feats[br], skips[br] = f, sk
+    fused = F.conv2d(torch.cat([feats["Q1"], feats["Q2"]], 1), sd[pre + "bottleneck_fuse.weight"])
+    fused = _blocks(sd, pre + "bottleneck_block.", fused, None, scan)
+    outs = []
+    for br in ("Q1", "Q2"):
+        f = F.conv2d(fused, sd[f"{pre}bottleneck_to_{br}.weight"])
+        for j in range(nl - 1):
+            d = f"{pre}decoders_{br}.{j}."
+            f = F.conv_transpose2d(f, sd[d + "up.weight"], sd[d + "up.bias"], stride=2)
+            f = F.conv2d(torch.cat([f, skips[br][nl - 2 - j]], 1), sd[d + "fuse.weight"])
+            f = _blocks(sd, d + "block.", f, None, scan)
+        outs.append(iwt_ref(F.conv2d(f, sd[f"{pre}proj_{br}.weight"], sd[f"{pre}proj_{br}.bias"], padding=1)))
+    return hamilton_ref(outs[0], outs[1])[:, 1:]
+
+
+def singlebranch_ref(sd: SD, x, scan=selective_scan_ref, pre: str = ""):
+    """DecompSingleBranch.forward (DecompSingleBranch_arch.py:195-237). Returns final_out."""
+    img, cond = x[:, :3], x[:, 3:]
+    q1, q2 = decomp_full_ref(sd, pre + "decomp.", img)
+    f = F.conv2d(torch.cat([q1, q2, cond], 1), sd[pre + "first_conv.weight"], sd[pre + "first_conv.bias"], padding=1)
+    nl = _levels(sd, pre + "down_layers.") + 1
+    sk = []
+    for i in range(nl - 1):
+        f = _blocks(sd, f"{pre}encoders.{i}.", f, None, scan)
+        sk.append(f)
+        f = F.conv2d(f, sd[f"{pre}down_layers.{i}.weight"], None, stride=2, padding=1)
+    f = _blocks(sd, pre + "bottleneck.", f, None, scan)
+    for j in range(nl - 1):
+        d = f"{pre}decoders.{j}."
+        f = F.conv_transpose2d(f, sd[d + "up.weight"], sd[d + "up.bias"], stride=2)
+        f = F.conv2d(torch.cat([f, sk[nl - 2 - j]], 1), sd[d + "fuse.weight"])
+        f = _blocks(sd, d + "block.", f, None, scan)
+    out = F.conv2d(f, sd[pre + "proj.weight"], sd[pre + "proj.bias"], padding=1)
+    return hamilton_ref(out[:, :4], out[:, 4:])[:, 1:]
+
+
+# ----------------------------------------------------------------------------------------------
+# A1/A2  Stage-I Bayesian U-Net     basicsr/archs/UNet_arch.py:58-82,97-155,245-361,364-474
+# ----------------------------------------------------------------------------------------------
+
+def patch_merging_ref(sd: SD, pre: str, x):
+    x = torch.cat([x[:, :, 0::2, 0::2], x[:, :, 1::2, 0::2], x[:, :, 0::2, 1::2], x[:, :, 1::2, 1::2]], 1)
+    return F.conv2d(layernorm2d_ref(x, sd[pre + "norm.weight"], sd[pre + "norm.bias"]), sd[pre + "reduction.weight"])
+
+
+def dual_upsample_ref(sd: SD, pre: str, x):
+    """DualUpSample(scale 2): pixel-shuffle branch || bilinear branch -> cat -> 1x1."""
+    p = F.conv2d(x, sd[pre + "up_p.0.weight"])
+    p = F.pixel_shuffle(F.prelu(p, sd[pre + "up_p.1.weight"]), 2)
+    p = F.conv2d(p, sd[pre + "up_p.3.weight"])
+    b = F.conv2d(x, sd[pre + "up_b.0.weight"], sd[pre + "up_b.0.bias"])
+    b = F.interpolate(F.prelu(b, sd[pre + "up_b.1.weight"]), scale_factor=2, mode="bilinear", align_corners=False)
+    b = F.conv2d(b, sd[pre + "up_b.3.weight"])
+    return F.conv2d(torch.cat([p, b], 1), sd[pre + "conv.weight"])
+
+
+def network_ref(sd: SD, x, src: Optional[EpsSource] = None, scan=selective_scan_ref, pre: str = ""):
+    """Network.forward in eval mode (mask path inactive), one SubNetwork (stage=1), use_pixelshuffle=True.
+    src=None -> deterministic (mu) prediction; otherwise weights are sampled layer by layer in
+    execution order, weight then bias (conv.py:106-110)."""
+    fea0 = F.conv2d(x, sd[pre + "first_conv.weight"], sd[pre + "first_conv.bias"], padding=1)
+    s = pre + "subnets.0."
+    nl = 0
+    while f"{s}encoder_layers.{nl}.0.blocks.0.norm.weight" in sd:
+        nl += 1
+    f, enc = fea0, []
+    for i in range(nl):
+        f = _blocks(sd, f"{s}encoder_layers.{i}.0.blocks.", f, src, scan)
+        enc.append(f)
+        f = patch_merging_ref(sd, f"{s}encoder_layers.{i}.1.", f)
+    f = _blocks(sd, s + "bottleneck.blocks.", f, src, scan)
+    for j in range(nl):
+        d = f"{s}decoder_layers.{j}."
+        f = dual_upsample_ref(sd, d + "0.", f)
+        f = F.conv2d(torch.cat([f, enc[nl - 1 - j]], 1), sd[d + "1.weight"])
+        f = _blocks(sd, d + "2.blocks.", f, src, scan)
+    f = fea0 + f
+    return F.conv2d(f, sd[pre + "proj.weight"], sd[pre + "proj.bias"], padding=1)
+
+
+# ----------------------------------------------------------------------------------------------
+# A0/A3/A4/A12  eval driver pieces         Enhancement/eval.py:146-153,170-176,199-297, utils.py:5-9
+# ----------------------------------------------------------------------------------------------
+
+def pad_reflect_ref(img_hwc, factor):
+    """_padimg_np (eval.py:146-153): reflect-pad bottom/right to the next multiple of ``factor``."""
+    import numpy as np
+    h, w = img_hwc.shape[:2]
+    ph = (((h + factor) // factor) * factor - h) if h % factor else 0
+    pw = (((w + factor) // factor) * factor - w) if w % factor else 0
+    return np.pad(img_hwc, ((0, ph), (0, pw), (0, 0)), "reflect") if (ph or pw) else img_hwc
+
+
+def cv2_resize_down(x, s):
+    """cv2.resize(img, None, fx=1/s, fy=1/s, INTER_LINEAR) for integer s on an NCHW tensor whose
+    H, W are multiples of s (eval.py:174).  With source coordinate (i+0.5)*s-0.5 the bilinear
+    taps are pixels s*i + s/2 - 1 and s*i + s/2 with weight 0.5 each (even s).  PARITY UNPINNED:
+    cv2 is not installed here; this is the definition of INTER_LINEAR without anti-aliasing."""
+    assert s % 2 == 0
+    a = s // 2 - 1
+    r = 0.5 * (x[:, :, a::s, :] + x[:, :, a + 1::s, :])
+    return 0.5 * (r[:, :, :, a::s] + r[:, :, :, a + 1::s])
+
+
+def psnr_ref(target, pred):
+    """Enhancement/utils.py:5-9 on float [0,1] arrays."""
+    import numpy as np
+    mse = float(np.mean((np.asarray(target) - np.asarray(pred)) ** 2))
+    return 100.0 if mse == 0 else 10.0 * math.log10(1.0 / mse)
+
+
+def eval_mc_ref(sd1: SD, sd2: SD, img, target, num_samples, *, scale=16, noise_level=0.1,
+                gt_mean=True, deterministic=False, eps_list=None, noise_list=None,
+                stage2=ddwavelet_ref, scan=selective_scan_ref, img_down=None, generator=None):
+    """The per-image Monte-Carlo loop of Enhancement/eval.py:170-297 (condition type 'mean',
+    full-reference selection with psnr_weight=1).
+
+    img, target: (1,3,h,w) float [0,1] tensors (target may be None when gt_mean=False).
+    eps_list[i]: recorded epsilon dict for Stage-I sample i (or None -> deterministic);
+    noise_list[i]: the (1,3,hp/scale,wp/scale) N(0,1) draw added to sample i's condition.
+    Returns dict(conds, preds (pre GT-mean, clamped), finals, psnr list, best index)."""
+    import numpy as np
+    _, _, h, w = img.shape
+    pad = torch.from_numpy(np.ascontiguousarray(
+        pad_reflect_ref(img[0].permute(1, 2, 0).numpy(), 4 * scale))).permute(2, 0, 1)[None]
+    if img_down is None:
+        img_down = cv2_resize_down(pad, scale)
+    if deterministic:
+        num_samples = 1
+    conds = []
+    for i in range(num_samples):
+        src = None if deterministic else EpsSource(None if eps_list is None else eps_list[i], generator)
+        c = network_ref(sd1, img_down, src, scan).clamp(0, 1)
+        if gt_mean:
+            c = (c * (target.mean(dim=(2, 3), keepdim=True) / c.mean(dim=(2, 3), keepdim=True))).clamp(0, 1)
+        nz = noise_list[i] if noise_list is not None else torch.randn(c.shape, generator=generator)
+        conds.append(c + nz * noise_level)
+    preds, finals, psnrs = [], [], []
+    tgt = None if target is None else target[0].permute(1, 2, 0).numpy()
+    for c in conds:
+        up = F.interpolate(c, scale_factor=scale, mode="bilinear", align_corners=False)
+        p = stage2(sd2, torch.cat([pad, up], 1), scan)[:, :, :h, :w].clamp(0, 1)
+        preds.append(p)
+        q = p[0].permute(1, 2, 0).numpy()
+        if gt_mean:
+            q = np.clip(q * (tgt.mean(axis=(0, 1), keepdims=True) / q.mean(axis=(0, 1), keepdims=True)), 0, 1)
+        finals.append(q)
+        if tgt is not None:
+            psnrs.append(psnr_ref(tgt, q))
+    best = 0
+    if psnrs:
+        rel = (np.array(psnrs) / max(psnrs)).tolist()      # eval.py:284 with psnr_weight=1
+        best = rel.index(max(rel))
+    return dict(img_down=img_down, conds=conds, preds=preds, finals=finals, psnr=psnrs, best=best)

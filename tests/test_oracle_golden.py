@@ -1,0 +1,100 @@
+"""CPU: the oracle (oracle/bem_oracle.py + the C scan) against golden vectors produced by the
+reference itself (tests/golden/make_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, qd_state_dict
+from oracle import bem_oracle as O
+
+
+def close(a, b, rtol=1e-5, atol=1e-6):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs().max().item()
+    assert torch.allclose(a, b, rtol=rtol, atol=atol), f"max abs err {err:.3e} (ref max {b.abs().max():.3e})"
+
+
+@pytest.mark.parametrize("tag", list("abcde"))
+@pytest.mark.parametrize("impl", ["py", "c"])
+def test_g1_selective_scan(tag, impl):
+    g = load_golden(f"g1_scan_{tag}")
+    fn = O.selective_scan_ref if impl == "py" else O.selective_scan_c
+    y = fn(g["u"], g["delta"], g["A"], g["B"], g["C"], g.get("D"), g.get("delta_bias"), True)
+    # reference kernel-test tolerance for f32 is rtol 6e-4 / atol 2e-3 (test_selective_scan.py:398-405);
+    # the restatement follows the same step order so it is held much tighter
+    close(y, g["y"], rtol=2e-5, atol=2e-5)
+
+
+def test_g2_cross_scan_merge():
+    g = load_golden("g2_cross")
+    assert torch.equal(O.cross_scan_ref(g["x"]), g["xs"])
+    close(O.cross_merge_ref(g["ys"]), g["y"], rtol=0, atol=1e-6)
+
+
+def test_g3_haar_quaternion():
+    g = load_golden("g3_haar")
+    close(O.dwt_ref(g["x"]), g["dwt"], rtol=0, atol=1e-6)
+    close(O.iwt_ref(g["x"]), g["iwt"], rtol=0, atol=1e-6)
+    close(O.hamilton_ref(g["p"], g["q"]), g["ham"], rtol=0, atol=1e-6)
+    # round trip property
+    close(O.iwt_ref(O.dwt_ref(g["x"])), g["x"], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("scan", ["py", "c"])
+def test_g4_vssblock(scan):
+    g = load_golden("g4_vssblock")
+    fn = O.selective_scan_ref if scan == "py" else O.selective_scan_c
+    sd = g["sd"]
+    ln = O.layernorm2d_ref(g["x"], sd["norm.weight"], sd["norm.bias"])
+    close(O.ss2d_ref(sd, "op.", ln, None, fn), g["y_ss2d"], rtol=1e-4, atol=1e-5)
+    close(O.vssblock_ref(sd, "", g["x"], None, fn), g["y"], rtol=1e-4, atol=1e-5)
+
+
+def test_g5_decomp():
+    g = load_golden("g5_decomp")
+    sd4, sd1 = qd_state_dict("model4", ""), qd_state_dict("model1", "")
+    q1w, q2w = O.decomp_wavelet_ref(sd4, "", g["img"])
+    close(q1w, g["q1w_model4"], rtol=1e-4, atol=1e-5)
+    close(q2w, g["q2w_model4"], rtol=1e-4, atol=1e-5)
+    for sd, tag in ((sd1, "model1"), (sd4, "model4")):
+        q1, q2 = O.decomp_full_ref(sd, "", g["img"])
+        close(q1, g[f"q1_{tag}"], rtol=1e-4, atol=1e-5)
+        close(q2, g[f"q2_{tag}"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag,fn,dm", [("ddw", O.ddwavelet_ref, "model4"), ("single", O.singlebranch_ref, "model1")])
+def test_g6_stage2(tag, fn, dm):
+    g = load_golden(f"g6_{tag}")
+    sd = dict(g["sd"])
+    sd.update(qd_state_dict(dm))
+    out = fn(sd, g["x"], O.selective_scan_c)
+    close(out, g["out"], rtol=1e-3, atol=2e-5)
+    close((out - g["gt"]).abs().mean(), g["loss"], rtol=1e-4, atol=1e-6)
+
+
+def test_g7_network_det_and_sampled():
+    g = load_golden("g7_network")
+    sd = g["sd"]
+    close(O.network_ref(sd, g["x"], None, O.selective_scan_c), g["y_det"], rtol=1e-3, atol=2e-5)
+    src = O.EpsSource({k if k.endswith(("weight", "bias")) else k: v for k, v in g["eps"].items()})
+    close(O.network_ref(sd, g["x"], src, O.selective_scan_c), g["y_sto"], rtol=1e-3, atol=2e-5)
+    # 6 Bayesian leaves per VSSBlock: in_proj, conv2d, out_proj, project_in, dwconv, project_out
+    names = [s.split(":")[0].rsplit(".", 1)[-1] for s in g["bnn_layers"]]
+    assert names[:6] == ["in_proj", "conv2d", "out_proj", "project_in", "dwconv", "project_out"]
+
+
+def test_g8_eval_loop():
+    g = load_golden("g8_eval")
+    sd2 = dict(g["sd2"])
+    sd2.update(qd_state_dict("model4"))
+    n = g["conds"].shape[0]
+    eps = [g[f"eps{i}"] for i in range(n)]
+    r = O.eval_mc_ref(g["sd1"], sd2, g["lq"], g["gt"], n, eps_list=eps,
+                      noise_list=[g["noises"][i:i + 1] for i in range(n)], scan=O.selective_scan_c)
+    close(r["img_down"], g["img_down"], rtol=0, atol=1e-7)
+    close(torch.cat(r["conds"]), g["conds"], rtol=1e-3, atol=5e-5)
+    close(torch.cat(r["preds"]), g["preds"], rtol=1e-3, atol=1e-4)
+    close(np.stack(r["finals"]), g["finals"], rtol=1e-3, atol=1e-4)
+    assert np.abs(np.array(r["psnr"]) - np.asarray(g["psnr"])).max() < 1e-3      # dB, the north-star parity bar
+    assert r["best"] == int(g["best"])
