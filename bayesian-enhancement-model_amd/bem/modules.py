@@ -1,0 +1,404 @@
+"""nn.Module mirrors of the reference's hot-path modules, computing through the HIP C ABI.
+
+Same class names, constructor arguments, parameter names/shapes (state-dict contract, SURVEY.md
+section 8b) and ``forward(x)`` meaning as the reference modules cited in each docstring -- but every
+forward is a sequence of hand-written gfx950 kernels (bem.ops).  There is no CPU implementation:
+calling a module on CPU tensors raises ``BemNativeError``.  Inference (forward) only in this round;
+the modules run under ``torch.no_grad`` semantics (outputs carry no autograd graph).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .native import BemNativeError
+
+
+# ------------------------------------------------------------------------------------------------
+# helpers
+# ------------------------------------------------------------------------------------------------
+class _Cache:
+    """Derived device tensors (packed / permuted weights) keyed on the source tensors' identity+version."""
+
+    def __init__(self):
+        self._d = {}
+
+    def get(self, key, srcs, fn):
+        sig = tuple((t.data_ptr(), t._version, t.device) for t in srcs)
+        hit = self._d.get(key)
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        with torch.no_grad():
+            val = fn()
+        self._d[key] = (sig, val)
+        return val
+
+
+def _need_cuda(x):
+    if not x.is_cuda:
+        raise BemNativeError("BEM modules run on the GPU through libbem_hip.so only (no CPU fallback); "
+                             "move the model and input to a HIP device")
+
+
+class SampleCtx:
+    """Per-forward Bayesian sampling context.
+
+    nsets: number of independent weight samples (= batch size: one per batch element) or 1 (shared);
+    eps:   optional {'<module path>.weight'|'.bias': tensor (nsets, *shape)} injected N(0,1) draws
+           (parity runs); when None the draws come from the in-kernel Philox stream (seed, counter).
+    """
+
+    def __init__(self, nsets: int, eps: Optional[Dict[str, torch.Tensor]] = None, seed: int = 0):
+        self.nsets, self.eps, self.seed = nsets, eps, seed
+        self.counter = 0
+
+    def next_stream(self):
+        self.counter += 1
+        return self.counter
+
+
+_SAMPLE_CTX: List[Optional[SampleCtx]] = [None]
+
+
+class sampling:
+    """``with sampling(SampleCtx(...)):`` scopes the Bayesian draws of the enclosed forwards."""
+
+    def __init__(self, ctx: Optional[SampleCtx]):
+        self.ctx = ctx
+
+    def __enter__(self):
+        self.prev = _SAMPLE_CTX[0]
+        _SAMPLE_CTX[0] = self.ctx
+        return self.ctx
+
+    def __exit__(self, *a):
+        _SAMPLE_CTX[0] = self.prev
+
+
+# ------------------------------------------------------------------------------------------------
+# leaves
+# ------------------------------------------------------------------------------------------------
+class LayerNorm2d(nn.LayerNorm):
+    """basicsr/vmamba/models/vmamba.py:58-63.  Parameter holder: the normalisation itself is always
+    fused into the prologue of the 1x1 GEMM that consumes it."""
+
+    def forward(self, x):
+        raise BemNativeError("LayerNorm2d is fused into its consumer GEMM; it has no standalone forward here")
+
+
+class Linear2d(nn.Linear):
+    """basicsr/vmamba/models/vmamba.py:42-55: 1x1 conv with a 2-D weight (4-D accepted on load)."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self._cache = _Cache()
+        self.module_path = ""
+
+    def _load_from_state_dict(self, state_dict, prefix, *args):
+        if prefix + "weight" in state_dict:
+            state_dict[prefix + "weight"] = state_dict[prefix + "weight"].view(self.weight.shape)
+        return super()._load_from_state_dict(state_dict, prefix, *args)
+
+    def gemm_weights(self, B):
+        Wp = self._cache.get("p", [self.weight], lambda: ops.pack_pw_weight(self.weight.detach().contiguous()))
+        return Wp, (self.bias.detach() if self.bias is not None else None)
+
+    def forward(self, x, **kw):
+        _need_cuda(x)
+        Wp, b = self.gemm_weights(x.shape[0])
+        return ops.pw_gemm(x, Wp, self.out_features, bias=b, **kw)
+
+
+class PwConv2d(nn.Conv2d):
+    """nn.Conv2d(kernel_size=1) holder running on the MFMA pointwise GEMM."""
+
+    def __init__(self, cin, cout, bias=True):
+        super().__init__(cin, cout, 1, 1, 0, bias=bias)
+        self._cache = _Cache()
+        self.module_path = ""
+
+    def gemm_weights(self, B):
+        Wp = self._cache.get("p", [self.weight], lambda: ops.pack_pw_weight(
+            self.weight.detach().reshape(self.out_channels, self.in_channels).contiguous()))
+        return Wp, (self.bias.detach() if self.bias is not None else None)
+
+    def forward(self, x, **kw):
+        _need_cuda(x)
+        Wp, b = self.gemm_weights(x.shape[0])
+        return ops.pw_gemm(x, Wp, self.out_channels, bias=b, **kw)
+
+
+class DwConv2d(nn.Conv2d):
+    """Depthwise 3x3, padding 1 (holder; epilogue chosen by the caller)."""
+
+    def __init__(self, ch, bias=True):
+        super().__init__(ch, ch, 3, 1, 1, groups=ch, bias=bias)
+        self.module_path = ""
+
+    def dw_weights(self, B):
+        return self.weight.detach(), (self.bias.detach() if self.bias is not None else None)
+
+
+class Conv2dK(nn.Conv2d):
+    """Dense conv (3x3 s1 p1 or 4x4 s2 p1) on the direct-conv kernel."""
+
+    def forward(self, x, relu=False, res1=None, res2=None, cin_slice=None):
+        _need_cuda(x)
+        return ops.conv2d(x, self.weight.detach(), None if self.bias is None else self.bias.detach(),
+                          stride=self.stride[0], pad=self.padding[0], relu=relu, res1=res1, res2=res2, cin_slice=cin_slice)
+
+
+class ConvT2x2(nn.ConvTranspose2d):
+    """nn.ConvTranspose2d(C, C/2, kernel 2, stride 2) = a 1x1 GEMM to 4*Cout rows + 2x2 scatter."""
+
+    def __init__(self, cin, cout):
+        super().__init__(cin, cout, kernel_size=2, stride=2, padding=0, output_padding=0)
+        self._cache = _Cache()
+
+    def forward(self, x):
+        _need_cuda(x)
+        co = self.out_channels
+
+        def prep():
+            w = self.weight.detach()                                  # (Cin, Cout, 2, 2)
+            w4 = w.permute(2, 3, 1, 0).reshape(4 * co, self.in_channels).contiguous()   # row = (dy*2+dx)*Co + co
+            return ops.pack_pw_weight(w4), self.bias.detach().repeat(4).contiguous()
+        Wp, b4 = self._cache.get("p", [self.weight, self.bias], prep)
+        return ops.pw_gemm(x, Wp, 4 * co, bias=b4, convT_Win=x.shape[3])
+
+
+# ------------------------------------------------------------------------------------------------
+# Bayesian leaves (basicsr/bayesian/conv.py:10-128, linear.py:8-104)
+# ------------------------------------------------------------------------------------------------
+class _BayesBase(nn.Module):
+    def _init_common(self, sigma_init, decay, bias):
+        self.deterministic = False
+        self.decay, self.sigma_init, self.step = decay, sigma_init, 0
+        self.bias = bias
+        self.module_path = ""
+        self._cache = _Cache()
+
+    def _rho_init(self):
+        return math.log(math.expm1(abs(self.sigma_init)) + 1e-20)
+
+    def _sampled(self, B):
+        """(weights (nsets,*shape), bias (nsets,C)|None, nsets) for this forward."""
+        ctx = _SAMPLE_CTX[0]
+        if self.deterministic:
+            return self.mu_weight.detach()[None], (self.mu_bias.detach()[None] if self.bias else None), 1
+        if self.training:
+            raise BemNativeError("Bayesian layers: training-mode forward (EMA prior + KL) is not part of this round")
+        if ctx is None:
+            ctx = SampleCtx(B, None, seed=torch.initial_seed() & 0xFFFFFFFF)
+        ns = ctx.nsets
+        ew = eb = None
+        if ctx.eps is not None:
+            ew = ctx.eps[self.module_path + ".weight"].contiguous()
+            if self.bias:
+                eb = ctx.eps[self.module_path + ".bias"].contiguous()
+        w = ops.bnn_sample(self.mu_weight.detach(), self.rho_weight.detach(), ns, ew, ctx.seed, ctx.next_stream())
+        b = None
+        if self.bias:
+            b = ops.bnn_sample(self.mu_bias.detach(), self.rho_bias.detach(), ns, eb, ctx.seed, ctx.next_stream())
+        return w, b, ns
+
+
+class Conv2dReparameterization(_BayesBase):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 sigma_init=0.05, decay=0.9998):
+        super().__init__()
+        self._init_common(sigma_init, decay, bias)
+        ks = kernel_size if isinstance(kernel_size, (tuple, list)) else (kernel_size, kernel_size)
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
+        self.stride, self.padding, self.dilation, self.groups = stride, padding, dilation, groups
+        shp = (out_channels, in_channels // groups, ks[0], ks[1])
+        self.mu_weight = nn.Parameter(torch.empty(shp))
+        self.rho_weight = nn.Parameter(torch.empty(shp))
+        if bias:
+            self.mu_bias = nn.Parameter(torch.empty(out_channels))
+            self.rho_bias = nn.Parameter(torch.empty(out_channels))
+        nn.init.kaiming_normal_(self.mu_weight, mode="fan_in", nonlinearity="leaky_relu")
+        self.rho_weight.data.fill_(self._rho_init())
+        if bias:
+            self.mu_bias.data.zero_()
+            self.rho_bias.data.fill_(self._rho_init())
+        self._is_dw = groups == in_channels and groups == out_channels and tuple(ks) == (3, 3)
+        self._is_pw = groups == 1 and tuple(ks) == (1, 1)
+        if not (self._is_dw or self._is_pw):
+            raise NotImplementedError("Bayesian conv: only 1x1 dense and 3x3 depthwise occur on the BEM path")
+
+    # pointwise interface
+    def gemm_weights(self, B):
+        w, b, ns = self._sampled(B)
+        Wp = ops.pack_pw_weight(w.reshape(ns, self.out_channels, self.in_channels).contiguous())
+        return Wp, b
+
+    # depthwise interface
+    def dw_weights(self, B):
+        w, b, ns = self._sampled(B)
+        return (w if ns > 1 else w[0]), (b if (b is None or ns > 1) else b[0])
+
+
+class Linear2dReparameterization(_BayesBase):
+    def __init__(self, in_features, out_features, bias=True, sigma_init=0.05, decay=0.9998):
+        super().__init__()
+        self._init_common(sigma_init, decay, bias)
+        self.in_features, self.out_features = in_features, out_features
+        self.mu_weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.rho_weight = nn.Parameter(torch.empty(out_features, in_features))
+        if bias:
+            self.mu_bias = nn.Parameter(torch.empty(out_features))
+            self.rho_bias = nn.Parameter(torch.empty(out_features))
+        nn.init.xavier_uniform_(self.mu_weight)
+        self.rho_weight.data.fill_(self._rho_init())
+        if bias:
+            self.mu_bias.data.zero_()
+            self.rho_bias.data.fill_(self._rho_init())
+
+    def gemm_weights(self, B):
+        w, b, ns = self._sampled(B)
+        return ops.pack_pw_weight(w.contiguous()), b
+
+
+# ------------------------------------------------------------------------------------------------
+# SS2D / gdMlp / VSSBlock  (basicsr/vmamba/models/vmamba.py:116-133, 438-716, 1241-1334)
+# ------------------------------------------------------------------------------------------------
+def _out_features(m):
+    return m.out_features if hasattr(m, "out_features") else m.out_channels
+
+
+class gdMlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0, channels_first=False):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.project_in = PwConv2d(in_features, hidden_features * 2)
+        self.dwconv = DwConv2d(hidden_features * 2)
+        self.project_out = PwConv2d(hidden_features, out_features)
+        self.act = act_layer()
+
+    def forward_fused(self, x, norm: LayerNorm2d):
+        """x + project_out(GELU(h1) * h2), h = dwconv(project_in(LN(x)))."""
+        B = x.shape[0]
+        Wp, b = self.project_in.gemm_weights(B)
+        t = ops.pw_gemm(x, Wp, _out_features(self.project_in), ln=(norm.weight.detach(), norm.bias.detach()),
+                        ln_eps=norm.eps, bias=b)
+        w, b = self.dwconv.dw_weights(B)
+        g = ops.dwconv3x3(t, w, b, mode=2)
+        Wp, b = self.project_out.gemm_weights(B)
+        return ops.pw_gemm(g, Wp, _out_features(self.project_out), bias=b, res=x)
+
+
+class SS2D(nn.Module):
+    """forward_type 'v05_noz' only (the one every arch on this path selects, UNet_arch.py:219)."""
+
+    def __init__(self, d_model=96, d_state=16, ssm_ratio=2.0, dt_rank="auto", act_layer=nn.SiLU, d_conv=3,
+                 conv_bias=True, dropout=0.0, bias=False, dt_min=0.001, dt_max=0.1, dt_init="random", dt_scale=1.0,
+                 dt_init_floor=1e-4, initialize="v0", forward_type="v2", channel_first=False, **kwargs):
+        super().__init__()
+        if forward_type != "v05_noz" or not channel_first or d_conv != 3 or initialize != "v0":
+            raise NotImplementedError("SS2D: only forward_type='v05_noz', channel_first, d_conv=3, init v0 are on the BEM path")
+        if int(d_state) != 1:
+            raise NotImplementedError("SS2D: the fused HIP scan is specialised for d_state = 1 (every shipped option file)")
+        d_inner = int(ssm_ratio * d_model)
+        R = math.ceil(d_model / 16) if dt_rank == "auto" else dt_rank
+        self.d_inner, self.dt_rank, self.d_state = d_inner, R, 1
+        self.in_proj = Linear2d(d_model, d_inner, bias=bias)
+        self.act = act_layer()
+        self.conv2d = DwConv2d(d_inner, bias=conv_bias)
+        K, N = 4, 1
+        self.x_proj_weight = nn.Parameter(torch.stack([nn.Linear(d_inner, R + 2 * N, bias=False).weight.detach() for _ in range(K)], 0))
+        self.out_proj = Linear2d(d_inner, d_model, bias=bias)
+        # mamba_init.init_dt_A_D (vmamba.py:222-289)
+        std = R ** -0.5 * dt_scale
+        dtw, dtb = [], []
+        for _ in range(K):
+            w = torch.empty(d_inner, R).uniform_(-std, std)
+            dt = torch.exp(torch.rand(d_inner) * (math.log(dt_max) - math.log(dt_min)) + math.log(dt_min)).clamp(min=dt_init_floor)
+            dtw.append(w)
+            dtb.append(dt + torch.log(-torch.expm1(-dt)))
+        self.dt_projs_weight = nn.Parameter(torch.stack(dtw, 0))
+        self.dt_projs_bias = nn.Parameter(torch.stack(dtb, 0))
+        self.A_logs = nn.Parameter(torch.log(torch.arange(1, N + 1, dtype=torch.float32)).view(1, -1).repeat(K * d_inner, 1).contiguous())
+        self.Ds = nn.Parameter(torch.ones(K * d_inner))
+        self.out_norm = LayerNorm2d(d_inner)
+        self._cache = _Cache()
+
+    def _scan_params(self):
+        R = self.dt_rank
+
+        def prep():
+            xw = self.x_proj_weight.detach()                                # (4, R+2, C)
+            w02 = ops.pack_pw_weight(torch.cat([xw[0], xw[2]], 0).contiguous())
+            w13 = ops.pack_pw_weight(torch.cat([xw[1], xw[3]], 0).contiguous())
+            A = (-torch.exp(self.A_logs.detach().float())).reshape(-1).contiguous()
+            return (w02, w13, self.dt_projs_weight.detach().contiguous(), self.dt_projs_bias.detach().contiguous(), A,
+                    self.Ds.detach().float().contiguous())
+        return self._cache.get("scan", [self.x_proj_weight, self.dt_projs_weight, self.dt_projs_bias, self.A_logs, self.Ds], prep)
+
+    def forward_fused(self, x, norm: LayerNorm2d):
+        """x + out_proj(out_norm(merge(scan(SiLU(dw(in_proj(LN(x))))))))  (vmamba.py:700-716 + 547-698)."""
+        B, C, H, W = x.shape
+        Ci, R, L = self.d_inner, self.dt_rank, H * W
+        Wp, b = self.in_proj.gemm_weights(B)
+        t = ops.pw_gemm(x, Wp, Ci, ln=(norm.weight.detach(), norm.bias.detach()), ln_eps=norm.eps, bias=b)
+        w, b = self.conv2d.dw_weights(B)
+        xc = ops.dwconv3x3(t, w, b, mode=1)
+        w02, w13, dtw, dtb, A, Ds = self._scan_params()
+        xcT = ops.transpose_planes(xc)
+        xd0 = ops.pw_gemm(xc, w02, 2 * (R + 2))
+        xd1 = ops.pw_gemm(xcT, w13, 2 * (R + 2))
+        y0, y1 = ops.ss2d_scan(xc.view(B, Ci, L), xcT.view(B, Ci, L), xd0.view(B, 2, R + 2, L), xd1.view(B, 2, R + 2, L),
+                               dtw, dtb, A, Ds)
+        y1r = ops.transpose_planes(y1.view(B, Ci, W, H))
+        Wp, b = self.out_proj.gemm_weights(B)
+        on = self.out_norm
+        return ops.pw_gemm(y0.view(B, Ci, H, W), Wp, _out_features(self.out_proj), x2=y1r, in_mode=1,
+                           ln=(on.weight.detach(), on.bias.detach()), ln_eps=on.eps, bias=b, res=x)
+
+    def forward(self, x):
+        raise BemNativeError("SS2D runs fused with its VSSBlock (norm prologue + residual epilogue); call the block")
+
+
+class VSSBlock(nn.Module):
+    def __init__(self, hidden_dim=0, drop_path=0.0, norm_layer=LayerNorm2d, channel_first=True, ssm_d_state=16,
+                 ssm_ratio=2.0, ssm_dt_rank="auto", ssm_act_layer=nn.SiLU, ssm_conv=3, ssm_conv_bias=True,
+                 ssm_drop_rate=0.0, ssm_init="v0", forward_type="v2", mlp_ratio=4.0, mlp_act_layer=nn.GELU,
+                 mlp_drop_rate=0.0, mlp_type="mlp", use_checkpoint=False, post_norm=False, grid_size=None, **kwargs):
+        super().__init__()
+        if post_norm or grid_size or drop_path or mlp_type != "gdmlp" or not channel_first:
+            raise NotImplementedError("VSSBlock: only pre-norm, gdmlp, channel-first, drop_path=0 are on the BEM path")
+        self.norm = LayerNorm2d(hidden_dim)
+        self.op = SS2D(d_model=hidden_dim, d_state=ssm_d_state, ssm_ratio=ssm_ratio, dt_rank=ssm_dt_rank,
+                       act_layer=ssm_act_layer, d_conv=ssm_conv, conv_bias=ssm_conv_bias, dropout=ssm_drop_rate,
+                       initialize=ssm_init, forward_type=forward_type, channel_first=channel_first)
+        self.drop_path = nn.Identity()
+        self.norm2 = LayerNorm2d(hidden_dim)
+        self.mlp = gdMlp(in_features=hidden_dim, hidden_features=int(hidden_dim * mlp_ratio), act_layer=mlp_act_layer,
+                         drop=mlp_drop_rate, channels_first=channel_first)
+
+    def forward(self, x):
+        _need_cuda(x)
+        x = x.contiguous()
+        x = self.op.forward_fused(x, self.norm)
+        return self.mlp.forward_fused(x, self.norm2)
+
+
+def make_vss_level(dim, num_block, d_state, ssm_ratio, mlp_ratio, mlp_type):
+    return nn.Sequential(*[VSSBlock(hidden_dim=dim, drop_path=0, norm_layer=LayerNorm2d, channel_first=True,
+                                    ssm_d_state=d_state, ssm_ratio=ssm_ratio, ssm_dt_rank="auto", ssm_act_layer=nn.SiLU,
+                                    ssm_conv=3, ssm_conv_bias=False, ssm_drop_rate=0, ssm_init="v0",
+                                    forward_type="v05_noz", mlp_ratio=mlp_ratio, mlp_act_layer=nn.GELU,
+                                    mlp_drop_rate=0.0, mlp_type=mlp_type, use_checkpoint=False, post_norm=False)
+                           for _ in range(num_block)])
+
+
+def set_module_paths(root: nn.Module):
+    """Record each leaf's dotted path (used as the key of injected epsilon draws)."""
+    for name, m in root.named_modules():
+        if hasattr(m, "module_path"):
+            m.module_path = name

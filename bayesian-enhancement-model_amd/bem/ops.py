@@ -1,0 +1,405 @@
+"""Tensor-level wrappers over the C ABI (include/bem_hip.h).
+
+Each wrapper checks operand shapes on the host before anything is launched (a kernel fault can take
+the whole GPU host down), allocates the output with torch (device memory is torch's job here) and
+launches on torch's current stream.  No wrapper computes anything itself."""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import native
+from .native import PwArgs, check, lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _chk(t: Optional[torch.Tensor], name: str, dtype=torch.float32, optional=False):
+    if t is None:
+        if optional:
+            return
+        raise ValueError(f"{name} is required")
+    if not t.is_cuda:
+        raise native.BemNativeError(f"{name} must be a CUDA/HIP tensor: the BEM hot path has no CPU implementation")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+
+
+# --------------------------------------------------------------------------- operator seam ----
+def selective_scan_fwd(u, delta, A, B, C, D=None, delta_bias=None, delta_softplus=True):
+    """u, delta (Bt,KC,L); A (KC,N); B, C (Bt,K,N,L); D, delta_bias (KC) -> y (Bt,KC,L) f32."""
+    for n, t in (("u", u), ("delta", delta), ("A", A), ("B", B), ("C", C)):
+        _chk(t, n)
+    _chk(D, "D", optional=True)
+    _chk(delta_bias, "delta_bias", optional=True)
+    Bt, KC, L = u.shape
+    if delta.shape != u.shape:
+        raise ValueError(f"delta {tuple(delta.shape)} != u {tuple(u.shape)}")
+    if B.dim() != 4 or B.shape[0] != Bt or B.shape[3] != L or C.shape != B.shape:
+        raise ValueError(f"B/C must be (batch, groups, dstate, L); got {tuple(B.shape)} {tuple(C.shape)}")
+    K, N = B.shape[1], B.shape[2]
+    if A.shape != (KC, N):
+        raise ValueError(f"A must be ({KC},{N}), got {tuple(A.shape)}")
+    if KC % K:
+        raise ValueError("dim must be a multiple of the number of groups")
+    for n, t in (("D", D), ("delta_bias", delta_bias)):
+        if t is not None and t.shape != (KC,):
+            raise ValueError(f"{n} must be ({KC},)")
+    out = torch.empty_like(u)
+    check(lib().bem_selective_scan_fwd_f32(_p(u), _p(delta), _p(A), _p(B), _p(C), _p(D), _p(delta_bias), _p(out),
+                                           Bt, KC, L, N, K, int(bool(delta_softplus)), _stream()), "selective_scan_fwd")
+    return out
+
+
+def cross_scan(x):
+    _chk(x, "x")
+    B, C, H, W = x.shape
+    xs = torch.empty(B, 4, C, H * W, device=x.device, dtype=x.dtype)
+    check(lib().bem_cross_scan_f32(_p(x), _p(xs), B, C, H, W, _stream()), "cross_scan")
+    return xs
+
+
+def cross_merge(ys):
+    _chk(ys, "ys")
+    B, K, C, H, W = ys.shape
+    if K != 4:
+        raise ValueError("cross_merge expects 4 directions")
+    y = torch.empty(B, C, H * W, device=ys.device, dtype=ys.dtype)
+    check(lib().bem_cross_merge_f32(_p(ys), _p(y), B, C, H, W, _stream()), "cross_merge")
+    return y
+
+
+# --------------------------------------------------------------------------- fused SS2D -------
+def ss2d_scan(x0, x1, xd0, xd1, dtw, dtb, A, Ds):
+    for n, t in (("x0", x0), ("x1", x1), ("xd0", xd0), ("xd1", xd1), ("dtw", dtw), ("dtb", dtb), ("A", A), ("Ds", Ds)):
+        _chk(t, n)
+    B, C, L = x0.shape
+    R = dtw.shape[2]
+    if x1.shape != x0.shape or xd0.shape != (B, 2, R + 2, L) or xd1.shape != xd0.shape:
+        raise ValueError(f"ss2d_scan shapes: x {tuple(x0.shape)}/{tuple(x1.shape)} xd {tuple(xd0.shape)}/{tuple(xd1.shape)} R={R}")
+    if dtw.shape != (4, C, R) or dtb.shape != (4, C) or A.numel() != 4 * C or Ds.numel() != 4 * C:
+        raise ValueError("ss2d_scan parameter shapes")
+    y0 = torch.empty_like(x0)
+    y1 = torch.empty_like(x0)
+    check(lib().bem_ss2d_scan_f32(_p(x0), _p(x1), _p(xd0), _p(xd1), _p(dtw), _p(dtb), _p(A), _p(Ds), _p(y0), _p(y1),
+                                  B, C, L, R, _stream()), "ss2d_scan")
+    return y0, y1
+
+
+# --------------------------------------------------------------------------- pointwise GEMM ---
+def packed_elems(M: int, K: int) -> int:
+    return int(lib().bem_pw_packed_elems(M, K))
+
+
+def pack_pw_weight(W):
+    """(M,K) or (nsets,M,K) natural weights -> packed MFMA operand order, shape (nsets, packed)."""
+    _chk(W, "W")
+    if W.dim() == 2:
+        W = W[None]
+    ns, M, K = W.shape
+    out = torch.empty(ns, packed_elems(M, K), device=W.device, dtype=W.dtype)
+    check(lib().bem_pack_pw_weight_f32(_p(W), _p(out), ns, M, K, _stream()), "pack_pw_weight")
+    return out
+
+
+def pw_gemm(x1, Wp, M, *, x2=None, in_mode=0, ln=None, ln_eps=1e-5, bias=None, res=None, prelu=None,
+            convT_Win: int = 0, out=None):
+    """x1 (B,C1,*spatial); Wp packed (1|B, packed(M,K)); returns (B,M,*spatial) (or (B,M/4,2H,2W) for convT)."""
+    _chk(x1, "x1"); _chk(Wp, "Wp"); _chk(x2, "x2", optional=True); _chk(bias, "bias", optional=True)
+    _chk(res, "res", optional=True); _chk(prelu, "prelu", optional=True)
+    B, C1 = x1.shape[0], x1.shape[1]
+    sp = tuple(x1.shape[2:])
+    L = 1
+    for s in sp:
+        L *= s
+    C2 = 0
+    if in_mode:
+        if x2 is None or x2.shape[0] != B or tuple(x2.shape[2:]) != sp:
+            raise ValueError("pw_gemm: x2 shape")
+        C2 = x2.shape[1]
+    K = C1 + C2 if in_mode == 2 else C1
+    if in_mode == 1 and C1 != C2:
+        raise ValueError("pw_gemm sum mode: channel mismatch")
+    if Wp.dim() != 2 or Wp.shape[1] != packed_elems(M, K) or Wp.shape[0] not in (1, B):
+        raise ValueError(f"pw_gemm: packed weight shape {tuple(Wp.shape)} does not match M={M} K={K} B={B}")
+    a = PwArgs()
+    a.x1, a.x2, a.C1, a.C2, a.in_mode = x1.data_ptr(), (x2.data_ptr() if x2 is not None else 0), C1, C2, in_mode
+    if ln is not None:
+        lw, lb = ln
+        _chk(lw, "ln_w"); _chk(lb, "ln_b")
+        if lw.numel() != K or lb.numel() != K:
+            raise ValueError("pw_gemm: LayerNorm size != K")
+        a.ln_w, a.ln_b = lw.data_ptr(), lb.data_ptr()
+    a.ln_eps = ln_eps
+    a.Wp, a.w_bstride = Wp.data_ptr(), (Wp.shape[1] if Wp.shape[0] > 1 else 0)
+    if bias is not None:
+        if bias.shape[-1] != M or (bias.dim() == 2 and bias.shape[0] not in (1, B)):
+            raise ValueError("pw_gemm: bias shape")
+        a.bias, a.bias_bstride = bias.data_ptr(), (M if (bias.dim() == 2 and bias.shape[0] > 1) else 0)
+    if prelu is not None:
+        if prelu.numel() != 1:
+            raise ValueError("pw_gemm: PReLU with one slope only")
+        a.prelu, a.act = prelu.data_ptr(), 1
+    if convT_Win:
+        if len(sp) != 2 or sp[1] != convT_Win or M % 4 or res is not None:
+            raise ValueError("pw_gemm convT mode: bad arguments")
+        oshape = (B, M // 4, 2 * sp[0], 2 * sp[1])
+        a.out_mode, a.Win = 1, convT_Win
+    else:
+        oshape = (B, M) + sp
+    if res is not None:
+        if tuple(res.shape) != oshape:
+            raise ValueError(f"pw_gemm: residual shape {tuple(res.shape)} != {oshape}")
+        a.res = res.data_ptr()
+    if out is None:
+        out = torch.empty(oshape, device=x1.device, dtype=x1.dtype)
+    elif tuple(out.shape) != oshape or not out.is_contiguous():
+        raise ValueError("pw_gemm: out shape")
+    a.out = out.data_ptr()
+    a.B, a.M, a.K, a.L = B, M, K, L
+    check(lib().bem_pw_gemm_f32(ctypes.byref(a), _stream()), "pw_gemm")
+    return out
+
+
+# --------------------------------------------------------------------------- convolutions -----
+def dwconv3x3(x, w, bias=None, mode=0):
+    """mode 0 plain, 1 SiLU, 2 gdMlp gate (x has 2*Cout channels), 3 PostSmooth.  w (Cw,1,3,3) or (B,Cw,1,3,3)."""
+    _chk(x, "x"); _chk(w, "w"); _chk(bias, "bias", optional=True)
+    B, Cin, H, W = x.shape
+    Cout = Cin // 2 if mode == 2 else Cin
+    per_b = w.dim() == 5
+    Cw = w.shape[1] if per_b else w.shape[0]
+    if Cw != Cin or tuple(w.shape[-3:]) != (1, 3, 3) or (per_b and w.shape[0] != B):
+        raise ValueError(f"dwconv3x3: weight {tuple(w.shape)} vs input channels {Cin}")
+    bb = 0
+    if bias is not None:
+        if bias.shape[-1] != Cin:
+            raise ValueError("dwconv3x3: bias shape")
+        bb = Cin if (bias.dim() == 2 and bias.shape[0] == B and B > 1) else 0
+        if bias.dim() == 2 and bias.shape[0] not in (1, B):
+            raise ValueError("dwconv3x3: bias batch")
+    out = torch.empty(B, Cout, H, W, device=x.device, dtype=x.dtype)
+    check(lib().bem_dwconv3x3_f32(_p(x), _p(w), (Cin * 9 if per_b else 0), _p(bias), bb, _p(out), B, Cout, H, W, mode,
+                                  _stream()), "dwconv3x3")
+    return out
+
+
+def conv2d(x, w, bias=None, stride=1, pad=1, relu=False, res1=None, res2=None, cin_slice=None):
+    """Dense conv.  ``cin_slice=(c0, Cin)`` convolves channels [c0, c0+Cin) of a wider contiguous x."""
+    _chk(x, "x"); _chk(w, "w"); _chk(bias, "bias", optional=True)
+    _chk(res1, "res1", optional=True); _chk(res2, "res2", optional=True)
+    B, Ct, H, W = x.shape
+    Cout, Cin, KH, KW = w.shape
+    c0 = 0
+    if cin_slice is not None:
+        c0, cs = cin_slice
+        if cs != Cin or c0 + Cin > Ct:
+            raise ValueError("conv2d: channel slice out of range")
+    elif Ct != Cin:
+        raise ValueError(f"conv2d: input has {Ct} channels, weight expects {Cin}")
+    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    out = torch.empty(B, Cout, Ho, Wo, device=x.device, dtype=x.dtype)
+    for n, r in (("res1", res1), ("res2", res2)):
+        if r is not None and r.shape != out.shape:
+            raise ValueError(f"conv2d: {n} shape")
+    if bias is not None and bias.shape != (Cout,):
+        raise ValueError("conv2d: bias shape")
+    xp = ctypes.c_void_p(x.data_ptr() + 4 * c0 * H * W)
+    check(lib().bem_conv2d_f32(xp, Ct * H * W, _p(w), _p(bias), _p(res1), _p(res2), _p(out), B, Cin, H, W, Cout, KH, KW,
+                               stride, pad, int(relu), _stream()), "conv2d")
+    return out
+
+
+# --------------------------------------------------------------------------- quaternion / Haar -
+def quat_dwt(x, c0=0):
+    """x (B,Ct,H,W); channels [c0,c0+3) are RGB -> (B,32,H/2,W/2)."""
+    _chk(x, "x")
+    B, Ct, H, W = x.shape
+    if c0 + 3 > Ct or H % 2 or W % 2:
+        raise ValueError("quat_dwt: needs 3 channels and even H, W")
+    out = torch.empty(B, 32, H // 2, W // 2, device=x.device, dtype=x.dtype)
+    check(lib().bem_quat_dwt_f32(ctypes.c_void_p(x.data_ptr() + 4 * c0 * H * W), Ct * H * W, _p(out), B, H, W, _stream()), "quat_dwt")
+    return out
+
+
+def dwt(x):
+    _chk(x, "x")
+    B, C, H, W = x.shape
+    if H % 2 or W % 2:
+        raise ValueError("dwt: even H, W required")
+    out = torch.empty(B, 4 * C, H // 2, W // 2, device=x.device, dtype=x.dtype)
+    check(lib().bem_dwt_f32(_p(x), _p(out), B, C, H, W, _stream()), "dwt")
+    return out
+
+
+def iwt(x):
+    _chk(x, "x")
+    B, C4, H, W = x.shape
+    if C4 % 4:
+        raise ValueError("iwt: channels must be a multiple of 4")
+    out = torch.empty(B, C4 // 4, 2 * H, 2 * W, device=x.device, dtype=x.dtype)
+    check(lib().bem_iwt_f32(_p(x), _p(out), B, C4, H, W, _stream()), "iwt")
+    return out
+
+
+def iwt_hamilton(q1w, q2w):
+    _chk(q1w, "q1w"); _chk(q2w, "q2w")
+    B, C, h, w = q1w.shape
+    if C != 16 or q2w.shape != q1w.shape:
+        raise ValueError("iwt_hamilton: expects two (B,16,h,w) tensors")
+    out = torch.empty(B, 3, 2 * h, 2 * w, device=q1w.device, dtype=q1w.dtype)
+    check(lib().bem_iwt_hamilton_f32(_p(q1w), _p(q2w), _p(out), B, h, w, _stream()), "iwt_hamilton")
+    return out
+
+
+def hamilton(q):
+    _chk(q, "q")
+    B, C, H, W = q.shape
+    if C != 8:
+        raise ValueError("hamilton: expects (B,8,H,W)")
+    out = torch.empty(B, 3, H, W, device=q.device, dtype=q.dtype)
+    check(lib().bem_hamilton_f32(_p(q), _p(out), B, H, W, _stream()), "hamilton")
+    return out
+
+
+def attn_fold(f1, f2, attn_w, fuse_w, fuse_b):
+    """Channel cross attention + fuse conv folded into per-image (32x64) weights: returns (Wp (B,2048), bias (B,32))."""
+    for n, t in (("f1", f1), ("f2", f2), ("attn_w", attn_w), ("fuse_w", fuse_w), ("fuse_b", fuse_b)):
+        _chk(t, n)
+    B, C, H, W = f1.shape
+    if C != 32 or f2.shape != f1.shape or attn_w.numel() != 8 * (32 * 32 + 32) or fuse_w.numel() != 32 * 64 or fuse_b.numel() != 32:
+        raise ValueError("attn_fold: shapes")
+    L = H * W
+    stats = torch.empty(B, 32 * 32 + 64, device=f1.device, dtype=torch.float64)
+    check(lib().bem_attn_stats_f64(_p(f1), _p(f2), _p(stats), B, L, _stream()), "attn_stats")
+    Wp = torch.empty(B, 32 * 64, device=f1.device, dtype=torch.float32)
+    bias = torch.empty(B, 32, device=f1.device, dtype=torch.float32)
+    check(lib().bem_attn_fold_f32(_p(stats), _p(attn_w), _p(fuse_w), _p(fuse_b), _p(Wp), _p(bias), B, L, _stream()), "attn_fold")
+    return Wp, bias
+
+
+# --------------------------------------------------------------------------- layout helpers ---
+def transpose_planes(x):
+    """(B,C,H,W) -> (B,C,W,H), contiguous."""
+    _chk(x, "x")
+    B, C, H, W = x.shape
+    out = torch.empty(B, C, W, H, device=x.device, dtype=x.dtype)
+    n = B * C
+    # plane count goes into gridDim.z (<= 65535): split large batches
+    step = 65535
+    xf, of = x.view(n, H * W), out.view(n, H * W)
+    for s in range(0, n, step):
+        m = min(step, n - s)
+        check(lib().bem_transpose_planes_f32(_p(xf[s:]), 0, _p(of[s:]), 0, 1, m, H, W, _stream()), "transpose_planes")
+    return out
+
+
+def copy_channels(src, dst, dst_c0, src_c0=0, C=None):
+    """dst[:, dst_c0:dst_c0+C] = src[:, src_c0:src_c0+C] (same spatial size)."""
+    _chk(src, "src"); _chk(dst, "dst")
+    B, Cs = src.shape[0], src.shape[1]
+    C = Cs - src_c0 if C is None else C
+    L = src[0, 0].numel()
+    if dst.shape[0] != B or dst[0, 0].numel() != L or dst_c0 + C > dst.shape[1] or src_c0 + C > Cs:
+        raise ValueError("copy_channels: shapes")
+    check(lib().bem_copy_channels_f32(ctypes.c_void_p(src.data_ptr() + 4 * src_c0 * L), Cs * L,
+                                      ctypes.c_void_p(dst.data_ptr() + 4 * dst_c0 * L), dst.shape[1] * L, B, C, L,
+                                      _stream()), "copy_channels")
+    return dst
+
+
+def bilinear_up(src, s, dst=None, dst_c0=0):
+    _chk(src, "src")
+    B, C, H, W = src.shape
+    if dst is None:
+        dst = torch.empty(B, C, H * s, W * s, device=src.device, dtype=src.dtype)
+        dst_c0 = 0
+    _chk(dst, "dst")
+    if dst.shape[0] != B or dst.shape[2] != H * s or dst.shape[3] != W * s or dst_c0 + C > dst.shape[1]:
+        raise ValueError("bilinear_up: dst shape")
+    Lo = H * s * W * s
+    check(lib().bem_bilinear_up_f32(_p(src), C * H * W, ctypes.c_void_p(dst.data_ptr() + 4 * dst_c0 * Lo),
+                                    dst.shape[1] * Lo, B, C, H, W, s, _stream()), "bilinear_up")
+    return dst
+
+
+def space_to_depth(x):
+    _chk(x, "x")
+    B, C, H, W = x.shape
+    if H % 2 or W % 2:
+        raise ValueError("space_to_depth: even H, W required")
+    out = torch.empty(B, 4 * C, H // 2, W // 2, device=x.device, dtype=x.dtype)
+    check(lib().bem_space_to_depth_f32(_p(x), _p(out), B, C, H, W, _stream()), "space_to_depth")
+    return out
+
+
+def pixel_shuffle2(x):
+    _chk(x, "x")
+    B, C4, H, W = x.shape
+    if C4 % 4:
+        raise ValueError("pixel_shuffle2: channels % 4")
+    out = torch.empty(B, C4 // 4, 2 * H, 2 * W, device=x.device, dtype=x.dtype)
+    check(lib().bem_pixel_shuffle2_f32(_p(x), _p(out), B, C4 // 4, H, W, _stream()), "pixel_shuffle2")
+    return out
+
+
+# --------------------------------------------------------------------------- Bayesian / MC ----
+def bnn_sample(mu, rho, nsets, eps=None, seed=0, stream_id=0):
+    """w[s] = mu + log1p(exp(rho)) * eps[s];  eps None -> Philox N(0,1) keyed by (seed, stream_id)."""
+    _chk(mu, "mu"); _chk(rho, "rho"); _chk(eps, "eps", optional=True)
+    n = mu.numel()
+    if rho.numel() != n or (eps is not None and eps.numel() != nsets * n):
+        raise ValueError("bnn_sample: shapes")
+    out = torch.empty((nsets,) + tuple(mu.shape), device=mu.device, dtype=mu.dtype)
+    check(lib().bem_bnn_sample_f32(_p(mu), _p(rho), _p(eps), _p(out), nsets, n, seed, stream_id, _stream()), "bnn_sample")
+    return out
+
+
+def plane_mean(x, h=None, w=None):
+    """Mean over the top-left (h,w) window of every (b,c) plane -> (B,C)."""
+    _chk(x, "x")
+    B, C, Hs, Ws = x.shape
+    h, w = h or Hs, w or Ws
+    out = torch.empty(B, C, device=x.device, dtype=x.dtype)
+    check(lib().bem_plane_mean_f32(_p(x), _p(out), B * C, Hs, Ws, h, w, _stream()), "plane_mean")
+    return out
+
+
+def cond_postproc(pred, target_mean, noise, samples_per_image, noise_level):
+    _chk(pred, "pred"); _chk(target_mean, "target_mean", optional=True); _chk(noise, "noise", optional=True)
+    Bn, C, h, w = pred.shape
+    if C != 3 or Bn % samples_per_image:
+        raise ValueError("cond_postproc: expects (Bn,3,h,w)")
+    if target_mean is not None and tuple(target_mean.shape) != (Bn // samples_per_image, 3):
+        raise ValueError("cond_postproc: target_mean shape")
+    if noise is not None and noise.shape != pred.shape:
+        raise ValueError("cond_postproc: noise shape")
+    out = torch.empty_like(pred)
+    check(lib().bem_cond_postproc_f32(_p(pred), _p(target_mean), _p(noise), _p(out), Bn, h, w, samples_per_image,
+                                      float(noise_level), _stream()), "cond_postproc")
+    return out
+
+
+def candidate_finalize(pred, target, samples_per_image, h, w, gt_mean):
+    """pred (Bn,3,Hp,Wp), target (n_img,3,h,w)|None -> (final (Bn,3,h,w), psnr (Bn))."""
+    _chk(pred, "pred"); _chk(target, "target", optional=True)
+    Bn, C, Hp, Wp = pred.shape
+    if C != 3 or Bn % samples_per_image or h > Hp or w > Wp:
+        raise ValueError("candidate_finalize: shapes")
+    if target is not None and tuple(target.shape) != (Bn // samples_per_image, 3, h, w):
+        raise ValueError("candidate_finalize: target shape")
+    fin = torch.empty(Bn, 3, h, w, device=pred.device, dtype=pred.dtype)
+    ps = torch.zeros(Bn, device=pred.device, dtype=pred.dtype)
+    check(lib().bem_candidate_finalize_f32(_p(pred), _p(target), _p(fin), _p(ps), Bn, samples_per_image, Hp, Wp, h, w,
+                                           int(bool(gt_mean)), _stream()), "candidate_finalize")
+    return fin, ps

@@ -1,0 +1,140 @@
+"""The two-stage N-sample Bayesian enhancement loop of Enhancement/eval.py:146-297, kept on the device.
+
+Differences from the reference driver that do not change results:
+  * all (image, sample) pairs of a call go through Stage-I and Stage-II as ONE batch -- every pair has
+    its own Bayesian weight sample (per-batch-element weights in the GEMM / depthwise kernels), which is
+    what the reference's B=1 loop draws (eval.py:199-211);
+  * Stage-I outputs never leave the GPU (the reference copies every sample D2H and back, eval.py:211,219);
+  * decomp(image) is evaluated once per image and shared by its N samples (it does not depend on the sample).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .modules import SampleCtx, sampling
+
+
+def pad_to_multiple(img: torch.Tensor, factor: int) -> torch.Tensor:
+    """_padimg_np (eval.py:146-153): reflect-pad bottom/right up to the next multiple of ``factor``.
+    Host-side image preparation in the reference (numpy); a torch indexing op here."""
+    h, w = img.shape[-2:]
+    ph = (((h + factor) // factor) * factor - h) if h % factor else 0
+    pw = (((w + factor) // factor) * factor - w) if w % factor else 0
+    return F.pad(img, (0, pw, 0, ph), mode="reflect") if (ph or pw) else img
+
+
+def resize_down_linear(img: torch.Tensor, s: int) -> torch.Tensor:
+    """cv2.resize(fx=fy=1/s, INTER_LINEAR) for even s on H, W multiples of s (eval.py:174): the mean of
+    the 2x2 centre taps of every s x s cell.  cv2 is unavailable here -> parity unpinned (oracle docstring)."""
+    a = s // 2 - 1
+    return 0.25 * (img[..., a::s, a::s] + img[..., a + 1::s, a::s] + img[..., a::s, a + 1::s] + img[..., a + 1::s, a + 1::s])
+
+
+class BEMPipeline:
+    """net1: Stage-I Bayesian ``Network`` (after convert2bnn), net2: Stage-II ``DecompDualBranchDDWavelet``."""
+
+    def __init__(self, net1, net2, scale_down: int = 16, noise_level: float = 0.1):
+        self.net1, self.net2 = net1, net2
+        self.scale, self.noise_level = scale_down, noise_level
+
+    @torch.no_grad()
+    def candidates(self, imgs, targets, num_samples: int, gt_mean: bool, deterministic: bool = False,
+                   eps: Optional[Dict[str, torch.Tensor]] = None, noise: Optional[torch.Tensor] = None,
+                   img_down: Optional[torch.Tensor] = None, seed: int = 0):
+        """imgs (B,3,h,w) in [0,1] on the GPU, targets (B,3,h,w) or None.
+        Returns dict(conds (B*N,3,hd,wd), raw (B*N,3,Hp,Wp), final (B*N,3,h,w), psnr (B*N)); row = image*N + sample."""
+        from basicsr.bayesian import set_prediction_type
+        B, _, h, w = imgs.shape
+        N = 1 if deterministic else num_samples
+        pad = pad_to_multiple(imgs, 4 * self.scale).contiguous()
+        Hp, Wp = pad.shape[-2:]
+        if img_down is None:
+            img_down = resize_down_linear(pad, self.scale)
+        x1 = img_down.repeat_interleave(N, dim=0).contiguous()                   # (B*N,3,hd,wd)
+        set_prediction_type(self.net1, deterministic)
+        with sampling(None if deterministic else SampleCtx(B * N, eps, seed)):
+            pred = self.net1(x1)[-1]
+        tmean = ops.plane_mean(targets.contiguous()) if (gt_mean and targets is not None) else None
+        if noise is None and self.noise_level:
+            noise = torch.randn(pred.shape, device=pred.device, dtype=pred.dtype)
+        conds = ops.cond_postproc(pred, tmean, noise if self.noise_level else None, N, self.noise_level)
+        cond_up = ops.bilinear_up(conds, self.scale)                             # (B*N,3,Hp,Wp)
+        d_img = self.net2.decompose(pad, 0)                                      # once per image
+        d_cond = self.net2.decompose(cond_up, 0)
+        raw = self.net2.forward_decomposed(d_img, d_cond, None if N == 1 else N)
+        final, psnr = ops.candidate_finalize(raw, None if targets is None else targets.contiguous(), N, h, w,
+                                             bool(gt_mean and targets is not None))
+        return dict(conds=conds, raw=raw, final=final, psnr=psnr, N=N)
+
+    @staticmethod
+    def select(psnr_rows: List[float]) -> int:
+        """eval.py:284-285 with psnr_weight = 1: index of the first maximum of psnr / max(psnr)."""
+        m = max(psnr_rows)
+        rel = [p / m for p in psnr_rows]
+        return rel.index(max(rel))
+
+    @torch.no_grad()
+    def enhance(self, imgs, targets, num_samples, gt_mean=True, deterministic=False, **kw):
+        r = self.candidates(imgs, targets, num_samples, gt_mean, deterministic, **kw)
+        B, N = imgs.shape[0], r["N"]
+        ps = r["psnr"].view(B, N).cpu().tolist()
+        best = [self.select(row) if targets is not None else 0 for row in ps]
+        idx = torch.tensor([i * N + b for i, b in enumerate(best)], device=imgs.device)
+        r.update(best=best, best_images=r["final"].index_select(0, idx), best_psnr=[ps[i][b] for i, b in enumerate(best)])
+        return r
+
+
+# ------------------------------------------------------------------------------------------------
+# small shared helpers (bench.py, smoke(), tests)
+# ------------------------------------------------------------------------------------------------
+def synthetic_pair(shape, seed=287128, device="cpu"):
+    """LOL-like dark input and bright target: lq = 0.25 U[0,1), gt = clamp(3.5 lq + 0.05 N)."""
+    g = torch.Generator().manual_seed(seed)
+    lq = 0.25 * torch.rand(shape, generator=g)
+    gt = (3.5 * lq + 0.05 * torch.randn(shape, generator=g)).clamp(0, 1)
+    return lq.to(device), gt.to(device)
+
+
+def build_nets(n_feat=40, num_blocks=(2, 2, 2), seed=100, device="cuda", stage2="DecompDualBranchDDWavelet", decomp="model4"):
+    """Seeded random-init Stage-I (Bayesian) and Stage-II nets through the registry, like eval.py:84-85."""
+    from basicsr.archs import build_network
+    from basicsr.bayesian import convert2bnn_selective
+    torch.manual_seed(seed)
+    common = dict(n_feat=n_feat, d_state=[1, 1, 1], ssm_ratio=1, mlp_ratio=4, mlp_type="gdmlp", use_pixelshuffle=True,
+                  drop_path=0.0, sam=False, stage=1, num_blocks=list(num_blocks))
+    net1 = build_network(dict(type="Network", in_channels=3, out_channels=3, **common))
+    convert2bnn_selective(net1, {"sigma_init": 0.05, "decay": 0.998, "pretrain": False})
+    net2 = build_network(dict(type=stage2, in_channels=6, out_channels=3, decomp_model=decomp, **common))
+    return net1.to(device).eval(), net2.to(device).eval()
+
+
+def smoke_check(verbose=False):
+    """1 image 60x52 (exercises reflect pad + crop), N = 2, reduced width, injected eps/noise:
+    HIP pipeline vs oracle.eval_mc_ref.  Raises AssertionError on mismatch."""
+    import numpy as np
+    from oracle import bem_oracle as O
+    net1, net2 = build_nets(n_feat=16, num_blocks=(1, 1, 1), seed=100, device="cuda")
+    sd1 = {k: v.detach().cpu() for k, v in net1.state_dict().items()}
+    sd2 = {k: v.detach().cpu() for k, v in net2.state_dict().items()}
+    lq, gt = synthetic_pair((1, 3, 60, 52))
+    N = 2
+    g = torch.Generator().manual_seed(7)
+    eps_cpu = [{k[:-len("mu_weight")] + "weight" if k.endswith("mu_weight") else k[:-len("mu_bias")] + "bias": torch.randn(v.shape, generator=g)
+                for k, v in sd1.items() if k.endswith(("mu_weight", "mu_bias"))} for _ in range(N)]
+    noise = torch.randn(N, 3, 4, 4, generator=g)
+    ref = O.eval_mc_ref(sd1, sd2, lq, gt, N, eps_list=eps_cpu, noise_list=[noise[i:i + 1] for i in range(N)], scan=O.selective_scan_c)
+    eps_dev = {k: torch.stack([e[k] for e in eps_cpu]).cuda() for k in eps_cpu[0]}
+    pipe = BEMPipeline(net1, net2)
+    out = pipe.enhance(lq.cuda(), gt.cuda(), N, gt_mean=True, eps=eps_dev, noise=noise.cuda())
+    fin = out["final"].cpu()
+    err = max(float((fin[i].permute(1, 2, 0) - torch.from_numpy(ref["finals"][i])).abs().max()) for i in range(N))
+    dps = float(np.abs(np.array(ref["psnr"]) - out["psnr"].cpu().numpy()).max())
+    if verbose:
+        print(f"smoke: candidates max|diff| = {err:.2e}, max PSNR diff = {dps:.2e} dB, best {out['best'][0]} (oracle {ref['best']})")
+    assert err < 5e-4 and dps < 1e-3, (err, dps)
+    assert out["best"][0] == ref["best"]
+    return err, dps

@@ -1,0 +1,38 @@
+// Shared helpers for the gfx950 kernels of libbem_hip.so (wave64 only, no other targets).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/bem_hip.h"
+
+#define BEM_WAVE 64
+
+extern thread_local char bem_err_buf[512];
+
+#define BEM_REQUIRE(cond, ...)                                              \
+    do {                                                                    \
+        if (!(cond)) {                                                      \
+            snprintf(bem_err_buf, sizeof(bem_err_buf), __VA_ARGS__);        \
+            return BEM_ERR_INVALID;                                         \
+        }                                                                   \
+    } while (0)
+
+static inline int bem_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(bem_err_buf, sizeof(bem_err_buf), "%s: %s", what, hipGetErrorString(e));
+        return BEM_ERR_LAUNCH;
+    }
+    return BEM_OK;
+}
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ float bem_softplus(float x) {
+    // F.softplus, threshold 20 (csms6s.py:54, selective_scan_fwd_kernel_oflex.cuh:125)
+    return x <= 20.f ? log1pf(expf(x)) : x;
+}
+__device__ __forceinline__ float bem_silu(float x) { return x / (1.f + expf(-x)); }
+__device__ __forceinline__ float bem_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }

@@ -1,0 +1,185 @@
+// Spatial convolutions: depthwise 3x3 (with fused SiLU / gated-GELU / PostSmooth epilogues) and a
+// dense direct convolution (3x3 s1, 4x4 s2, ...) staged through LDS.
+#include "bem_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// depthwise 3x3, pad 1.  grid (ceil(H*W4/256), Cout, B); each thread produces 4 consecutive pixels.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dw_rows(const float* __restrict__ plane, int H, int W, int y, int x0,
+                                        const float* __restrict__ w9, float (&acc)[4]) {
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= H) continue;
+        const float* r = plane + (int64_t)yy * W;
+        float v[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int xx = x0 - 1 + i;
+            v[i] = (xx >= 0 && xx < W) ? r[xx] : 0.f;
+        }
+        const float w0 = w9[(dy + 1) * 3], w1 = w9[(dy + 1) * 3 + 1], w2 = w9[(dy + 1) * 3 + 2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = fmaf(w0, v[j], fmaf(w1, v[j + 1], fmaf(w2, v[j + 2], acc[j])));
+    }
+}
+
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        int64_t w_bs, const float* __restrict__ bias, int64_t b_bs,
+                                                        float* __restrict__ out, int Cout, int H, int W, int mode) {
+    const int W4 = (W + 3) >> 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= H * W4) return;
+    const int y = i / W4, x0 = (i - y * W4) * 4;
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int Cin = (mode == 2) ? 2 * Cout : Cout;
+    const int64_t HW = (int64_t)H * W;
+    const float* wb = w + (int64_t)b * w_bs;
+    const float* bb = bias ? bias + (int64_t)b * b_bs : nullptr;
+    float a0[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* pl = x + ((int64_t)b * Cin + c) * HW;
+    dw_rows(pl, H, W, y, x0, wb + (int64_t)c * 9, a0);
+    const float b0 = bb ? bb[c] : 0.f;
+    float o[4];
+    if (mode == 2) {
+        float a1[4] = {0.f, 0.f, 0.f, 0.f};
+        dw_rows(x + ((int64_t)b * Cin + c + Cout) * HW, H, W, y, x0, wb + (int64_t)(c + Cout) * 9, a1);
+        const float b1 = bb ? bb[c + Cout] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = bem_gelu(a0[j] + b0) * (a1[j] + b1);
+    } else if (mode == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = bem_silu(a0[j] + b0);
+    } else if (mode == 3) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int xx = x0 + j;
+            const float xv = xx < W ? pl[(int64_t)y * W + xx] : 0.f;
+            o[j] = xv + fmaxf(a0[j] + b0, 0.f);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = a0[j] + b0;
+    }
+    float* op = out + ((int64_t)b * Cout + c) * HW + (int64_t)y * W + x0;
+    if ((W & 3) == 0) {
+        *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (x0 + j < W) op[j] = o[j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dense direct conv.  Workgroup = 256 threads = 8 x 32 output pixels, COB output channels per
+// workgroup, input channels streamed through LDS in chunks of CIB (patch + weights).
+// ------------------------------------------------------------------------------------------------
+constexpr int TH = 8, TW = 32, COB = 16, CIB = 8;
+
+template <int KH, int KW, int S>
+__global__ __launch_bounds__(256) void conv2d_kernel(const float* __restrict__ x, int64_t x_bs,
+                                                     const float* __restrict__ w, const float* __restrict__ bias,
+                                                     const float* __restrict__ res1, const float* __restrict__ res2,
+                                                     float* __restrict__ out, int Cin, int H, int W, int Cout,
+                                                     int Ho, int Wo, int pad, int relu, int tilesX) {
+    constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW;
+    constexpr int PWP = PW + 1;                       // +1 pad: rows of a patch start on different banks
+    __shared__ float patch[CIB][PH][PWP];
+    __shared__ __attribute__((aligned(16))) float wl[CIB][KH * KW][COB];
+    const int tile = blockIdx.x;
+    const int ty0 = (tile / tilesX) * TH, tx0 = (tile % tilesX) * TW;
+    const int co0 = blockIdx.y * COB;
+    const int b = blockIdx.z;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int oy = ty0 + ty, ox = tx0 + tx;
+    const int iy0 = ty0 * S - pad, ix0 = tx0 * S - pad;
+    const float* xb = x + (int64_t)b * x_bs;
+    float acc[COB];
+#pragma unroll
+    for (int i = 0; i < COB; ++i) acc[i] = 0.f;
+    for (int ci0 = 0; ci0 < Cin; ci0 += CIB) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < CIB * PH * PW; i += 256) {
+            const int cc = i / (PH * PW), rem = i - cc * (PH * PW);
+            const int py = rem / PW, px = rem - py * PW;
+            const int ci = ci0 + cc, iy = iy0 + py, ix = ix0 + px;
+            float v = 0.f;
+            if (ci < Cin && iy >= 0 && iy < H && ix >= 0 && ix < W) v = xb[((int64_t)ci * H + iy) * W + ix];
+            patch[cc][py][px] = v;
+        }
+        for (int i = threadIdx.x; i < CIB * KH * KW * COB; i += 256) {
+            const int o = i % COB, t = (i / COB) % (KH * KW), cc = i / (COB * KH * KW);
+            const int ci = ci0 + cc, co = co0 + o;
+            wl[cc][t][o] = (ci < Cin && co < Cout) ? w[(((int64_t)co * Cin + ci) * KH * KW) + t] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int cc = 0; cc < CIB; ++cc) {
+#pragma unroll
+            for (int ky = 0; ky < KH; ++ky) {
+#pragma unroll
+                for (int kx = 0; kx < KW; ++kx) {
+                    const float v = patch[cc][ty * S + ky][tx * S + kx];
+                    const float4* wq = reinterpret_cast<const float4*>(&wl[cc][ky * KW + kx][0]);
+#pragma unroll
+                    for (int q = 0; q < COB / 4; ++q) {
+                        const float4 ww = wq[q];
+                        acc[4 * q] = fmaf(ww.x, v, acc[4 * q]);
+                        acc[4 * q + 1] = fmaf(ww.y, v, acc[4 * q + 1]);
+                        acc[4 * q + 2] = fmaf(ww.z, v, acc[4 * q + 2]);
+                        acc[4 * q + 3] = fmaf(ww.w, v, acc[4 * q + 3]);
+                    }
+                }
+            }
+        }
+    }
+    if (oy >= Ho || ox >= Wo) return;
+#pragma unroll
+    for (int o = 0; o < COB; ++o) {
+        const int co = co0 + o;
+        if (co >= Cout) break;
+        float v = acc[o] + (bias ? bias[co] : 0.f);
+        if (relu) v = fmaxf(v, 0.f);
+        const int64_t idx = (((int64_t)b * Cout + co) * Ho + oy) * Wo + ox;
+        if (res1) v += res1[idx];
+        if (res2) v += res2[idx];
+        out[idx] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int bem_dwconv3x3_f32(const float* x, const float* w, int64_t w_bstride, const float* bias,
+                                 int64_t bias_bstride, float* out, int B, int Cout, int H, int W, int mode,
+                                 void* stream) {
+    BEM_REQUIRE(x && w && out, "dwconv3x3: null tensor");
+    BEM_REQUIRE(B >= 0 && B <= 65535 && Cout > 0 && Cout <= 65535 && H > 0 && W > 0, "dwconv3x3: bad shape");
+    BEM_REQUIRE(mode >= 0 && mode <= 3, "dwconv3x3: mode %d", mode);
+    if (B == 0) return BEM_OK;
+    dim3 grid(cdiv(H * ((W + 3) / 4), 256), Cout, B);
+    dwconv3x3_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, w, w_bstride, bias, bias_bstride, out, Cout, H, W, mode);
+    return bem_check_launch("dwconv3x3");
+}
+
+extern "C" int bem_conv2d_f32(const float* x, int64_t x_bstride, const float* w, const float* bias,
+                              const float* res1, const float* res2, float* out, int B, int Cin, int H, int W,
+                              int Cout, int KH, int KW, int stride, int pad, int relu, void* stream) {
+    BEM_REQUIRE(x && w && out, "conv2d: null tensor");
+    BEM_REQUIRE(B >= 0 && B <= 65535 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "conv2d: bad shape");
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    BEM_REQUIRE(Ho > 0 && Wo > 0, "conv2d: empty output");
+    if (B == 0) return BEM_OK;
+    const int tilesX = cdiv(Wo, TW), tilesY = cdiv(Ho, TH);
+    dim3 grid(tilesX * tilesY, cdiv(Cout, COB), B);
+    hipStream_t s = (hipStream_t)stream;
+    if (KH == 3 && KW == 3 && stride == 1)
+        conv2d_kernel<3, 3, 1><<<grid, 256, 0, s>>>(x, x_bstride, w, bias, res1, res2, out, Cin, H, W, Cout, Ho, Wo, pad, relu, tilesX);
+    else if (KH == 4 && KW == 4 && stride == 2)
+        conv2d_kernel<4, 4, 2><<<grid, 256, 0, s>>>(x, x_bstride, w, bias, res1, res2, out, Cin, H, W, Cout, Ho, Wo, pad, relu, tilesX);
+    else
+        BEM_REQUIRE(false, "conv2d: unsupported kernel %dx%d stride %d (have 3x3 s1, 4x4 s2)", KH, KW, stride);
+    return bem_check_launch("conv2d");
+}

@@ -1,0 +1,644 @@
+// Bandwidth-bound helpers: quaternion/Haar primitives, channel-attention statistics + weight folding,
+// layout shuffles, bilinear resampling, Bayesian weight sampling, Monte-Carlo loop reductions.
+#include "bem_common.h"
+
+thread_local char bem_err_buf[512] = "";
+extern "C" const char* bem_last_error(void) { return bem_err_buf; }
+extern "C" int bem_abi_version(void) { return 1; }
+
+namespace {
+
+#define GRID1D(n) dim3((unsigned)cdiv64((n), 256))
+
+// ---------------------------------------------------------------- quaternion + Haar ----------
+// One thread per output (half-res) pixel: reads the 2x2 RGB block, forms the 8-channel quaternion
+// stack and writes the 4 Haar bands (QD/model4.py:7-18,216-236).
+__global__ void quat_dwt_kernel(const float* __restrict__ rgb, int64_t x_bs, float* __restrict__ out, int H, int W,
+                                int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int h2 = H >> 1, w2 = W >> 1;
+    const int x = (int)(i % w2), y = (int)((i / w2) % h2), b = (int)(i / ((int64_t)w2 * h2));
+    const float* p = rgb + (int64_t)b * x_bs;
+    const int64_t HW = (int64_t)H * W;
+    float q[8][4];   // [channel][a: (even row, even col), b: (odd row, even col), c: (even, odd), d: (odd, odd)]
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int yy = 2 * y + (s & 1), xx = 2 * x + (s >> 1);
+        const float r = p[(int64_t)yy * W + xx], g = p[HW + (int64_t)yy * W + xx], bl = p[2 * HW + (int64_t)yy * W + xx];
+        const float den = fmaxf(fmaxf(r, g), bl) + 1e-7f;
+        q[0][s] = 0.f; q[1][s] = 0.f;
+        q[2][s] = r / den; q[3][s] = r;
+        q[4][s] = g / den; q[5][s] = g;
+        q[6][s] = bl / den; q[7][s] = bl;
+    }
+    const int64_t hw2 = (int64_t)h2 * w2;
+    float* o = out + (int64_t)b * 32 * hw2 + (int64_t)y * w2 + x;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float a = q[c][0] / 2, bb = q[c][1] / 2, cc = q[c][2] / 2, d = q[c][3] / 2;
+        o[(int64_t)(c) * hw2] = a + bb + cc + d;
+        o[(int64_t)(8 + c) * hw2] = -a - bb + cc + d;
+        o[(int64_t)(16 + c) * hw2] = -a + bb - cc + d;
+        o[(int64_t)(24 + c) * hw2] = a - bb - cc + d;
+    }
+}
+
+__global__ void dwt_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int H, int W, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int h2 = H >> 1, w2 = W >> 1;
+    const int xx = (int)(i % w2), y = (int)((i / w2) % h2);
+    const int c = (int)((i / ((int64_t)w2 * h2)) % C), b = (int)(i / ((int64_t)w2 * h2 * C));
+    const float* p = x + ((int64_t)b * C + c) * H * W;
+    const float a = p[(int64_t)(2 * y) * W + 2 * xx] / 2, bb = p[(int64_t)(2 * y + 1) * W + 2 * xx] / 2;
+    const float cc = p[(int64_t)(2 * y) * W + 2 * xx + 1] / 2, d = p[(int64_t)(2 * y + 1) * W + 2 * xx + 1] / 2;
+    const int64_t hw2 = (int64_t)h2 * w2;
+    float* o = out + ((int64_t)b * 4 * C + c) * hw2 + (int64_t)y * w2 + xx;
+    o[0] = a + bb + cc + d;
+    o[(int64_t)C * hw2] = -a - bb + cc + d;
+    o[(int64_t)2 * C * hw2] = -a + bb - cc + d;
+    o[(int64_t)3 * C * hw2] = a - bb - cc + d;
+}
+
+__device__ __forceinline__ void iwt4(float ll, float hl, float lh, float hh, float (&o)[4]) {
+    // o[0]=(even row, even col) o[1]=(odd row, even col) o[2]=(even, odd) o[3]=(odd, odd)  (model4.py:26-35)
+    ll /= 2; hl /= 2; lh /= 2; hh /= 2;
+    o[0] = ll - hl - lh + hh;
+    o[1] = ll - hl + lh - hh;
+    o[2] = ll + hl - lh - hh;
+    o[3] = ll + hl + lh + hh;
+}
+
+__global__ void iwt_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int H, int W, int64_t total) {
+    // x (B,4C,H,W) -> out (B,C,2H,2W); one thread per input pixel and channel
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int xx = (int)(i % W), y = (int)((i / W) % H);
+    const int c = (int)((i / ((int64_t)W * H)) % C), b = (int)(i / ((int64_t)W * H * C));
+    const int64_t hw = (int64_t)H * W;
+    const float* p = x + ((int64_t)b * 4 * C + c) * hw + (int64_t)y * W + xx;
+    float o[4];
+    iwt4(p[0], p[(int64_t)C * hw], p[(int64_t)2 * C * hw], p[(int64_t)3 * C * hw], o);
+    float* q = out + ((int64_t)b * C + c) * 4 * hw + (int64_t)(2 * y) * (2 * W) + 2 * xx;
+    *reinterpret_cast<float2*>(q) = make_float2(o[0], o[2]);
+    *reinterpret_cast<float2*>(q + 2 * W) = make_float2(o[1], o[3]);
+}
+
+__device__ __forceinline__ void hamilton_ijk(const float (&p)[4], const float (&q)[4], float (&o)[3]) {
+    o[0] = p[0] * q[1] + p[1] * q[0] + p[2] * q[3] - p[3] * q[2];
+    o[1] = p[0] * q[2] - p[1] * q[3] + p[2] * q[0] + p[3] * q[1];
+    o[2] = p[0] * q[3] + p[1] * q[2] - p[2] * q[1] + p[3] * q[0];
+}
+
+__global__ void iwt_hamilton_kernel(const float* __restrict__ q1w, const float* __restrict__ q2w,
+                                    float* __restrict__ out, int h, int w, int64_t total) {
+    // q*w (B,16,h,w): channel = band*4 + component.  out (B,3,2h,2w).
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % w), y = (int)((i / w) % h), b = (int)(i / ((int64_t)w * h));
+    const int64_t hw = (int64_t)h * w;
+    const float* a = q1w + (int64_t)b * 16 * hw + (int64_t)y * w + x;
+    const float* c = q2w + (int64_t)b * 16 * hw + (int64_t)y * w + x;
+    float P[4][4], Q[4][4];   // [component][sub-pixel]
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        iwt4(a[(int64_t)k * hw], a[(int64_t)(4 + k) * hw], a[(int64_t)(8 + k) * hw], a[(int64_t)(12 + k) * hw], P[k]);
+        iwt4(c[(int64_t)k * hw], c[(int64_t)(4 + k) * hw], c[(int64_t)(8 + k) * hw], c[(int64_t)(12 + k) * hw], Q[k]);
+    }
+    float res[3][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const float pp[4] = {P[0][s], P[1][s], P[2][s], P[3][s]};
+        const float qq[4] = {Q[0][s], Q[1][s], Q[2][s], Q[3][s]};
+        float o[3];
+        hamilton_ijk(pp, qq, o);
+        res[0][s] = o[0]; res[1][s] = o[1]; res[2][s] = o[2];
+    }
+    const int W2 = 2 * w;
+    float* op = out + (int64_t)b * 3 * 4 * hw + (int64_t)(2 * y) * W2 + 2 * x;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float* o = op + (int64_t)k * 4 * hw;
+        *reinterpret_cast<float2*>(o) = make_float2(res[k][0], res[k][2]);
+        *reinterpret_cast<float2*>(o + W2) = make_float2(res[k][1], res[k][3]);
+    }
+}
+
+__global__ void hamilton_kernel(const float* __restrict__ q, float* __restrict__ out, int64_t HW, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t pix = i % HW, b = i / HW;
+    const float* p = q + b * 8 * HW + pix;
+    const float pp[4] = {p[0], p[HW], p[2 * HW], p[3 * HW]};
+    const float qq[4] = {p[4 * HW], p[5 * HW], p[6 * HW], p[7 * HW]};
+    float o[3];
+    hamilton_ijk(pp, qq, o);
+    float* op = out + b * 3 * HW + pix;
+    op[0] = o[0]; op[HW] = o[1]; op[2 * HW] = o[2];
+}
+
+// ---------------------------------------------------------------- channel attention ----------
+// stats[b] = { S[32][32] = F1 F2^T, s1[32] = F1 1, s2[32] = F2 1 } accumulated in f64.
+constexpr int ATT_C = 32;
+constexpr int ATT_CHUNK = 2048;
+__global__ __launch_bounds__(256) void attn_stats_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                         double* __restrict__ stats, int L) {
+    __shared__ float t1[ATT_C][65], t2[ATT_C][65];
+    const int b = blockIdx.y;
+    const int p0 = blockIdx.x * ATT_CHUNK;
+    const int i0 = (threadIdx.x >> 4) * 2, j0 = (threadIdx.x & 15) * 2;
+    double a00 = 0, a01 = 0, a10 = 0, a11 = 0, r0 = 0, r1 = 0, c0 = 0, c1 = 0;
+    const float* F1 = f1 + (int64_t)b * ATT_C * L;
+    const float* F2 = f2 + (int64_t)b * ATT_C * L;
+    const int pend = min(p0 + ATT_CHUNK, L);
+    for (int ps = p0; ps < pend; ps += 64) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < ATT_C * 64; i += 256) {
+            const int c = i >> 6, pp = i & 63;
+            const int p = ps + pp;
+            t1[c][pp] = p < pend ? F1[(int64_t)c * L + p] : 0.f;
+            t2[c][pp] = p < pend ? F2[(int64_t)c * L + p] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int pp = 0; pp < 64; ++pp) {
+            const double u0 = t1[i0][pp], u1 = t1[i0 + 1][pp], v0 = t2[j0][pp], v1 = t2[j0 + 1][pp];
+            a00 = fma(u0, v0, a00); a01 = fma(u0, v1, a01); a10 = fma(u1, v0, a10); a11 = fma(u1, v1, a11);
+            if (j0 == 0) { r0 += u0; r1 += u1; }
+            if (i0 == 0) { c0 += v0; c1 += v1; }
+        }
+    }
+    double* S = stats + (int64_t)b * (ATT_C * ATT_C + 2 * ATT_C);
+    atomicAdd(&S[i0 * ATT_C + j0], a00);
+    atomicAdd(&S[i0 * ATT_C + j0 + 1], a01);
+    atomicAdd(&S[(i0 + 1) * ATT_C + j0], a10);
+    atomicAdd(&S[(i0 + 1) * ATT_C + j0 + 1], a11);
+    if (j0 == 0) { atomicAdd(&S[ATT_C * ATT_C + i0], r0); atomicAdd(&S[ATT_C * ATT_C + i0 + 1], r1); }
+    if (i0 == 0) { atomicAdd(&S[ATT_C * ATT_C + ATT_C + j0], c0); atomicAdd(&S[ATT_C * ATT_C + ATT_C + j0 + 1], c1); }
+}
+
+// One workgroup of 32x32 threads per image; thread (i, j) owns entry [i][j] of every 32x32 product.
+__device__ __forceinline__ double mm(const double (*A)[33], const double (*Bm)[33], int i, int j) {
+    double s = 0;
+#pragma unroll 8
+    for (int k = 0; k < ATT_C; ++k) s = fma(A[i][k], Bm[k][j], s);
+    return s;
+}
+
+__global__ __launch_bounds__(1024) void attn_fold_kernel(const double* __restrict__ stats, const float* __restrict__ aw,
+                                                         const float* __restrict__ fw, const float* __restrict__ fb,
+                                                         float* __restrict__ Wp, float* __restrict__ bias_out, int L) {
+    __shared__ double X[ATT_C][33], Y[ATT_C][33], Z[ATT_C][33], M1[ATT_C][33], M2[ATT_C][33];
+    __shared__ double va[ATT_C], vb[ATT_C], c1[ATT_C], c2[ATT_C], rowred[ATT_C];
+    const int i = threadIdx.x >> 5, j = threadIdx.x & 31;
+    const int b = blockIdx.x;
+    const double* S = stats + (int64_t)b * (ATT_C * ATT_C + 2 * ATT_C);
+    const double* s1 = S + ATT_C * ATT_C;
+    const double* s2 = s1 + ATT_C;
+    constexpr int WSZ = ATT_C * ATT_C + ATT_C;
+    auto Wm = [&](int m, int r, int c) -> double { return (double)aw[m * WSZ + r * ATT_C + c]; };
+    auto Bv = [&](int m, int r) -> double { return (double)aw[m * WSZ + ATT_C * ATT_C + r]; };
+    // indices into attn_w: 0 q1, 1 k2, 2 v2, 3 q2, 4 k1, 5 v1, 6 out1, 7 out2
+    const double scale = 1.0 / sqrt((double)ATT_C);
+    for (int br = 0; br < 2; ++br) {
+        const int mq = br ? 3 : 0, mk = br ? 4 : 1, mv = br ? 5 : 2, mo = br ? 7 : 6;
+        const double* sq = br ? s2 : s1;   // sums of the tensor feeding q
+        const double* sk = br ? s1 : s2;   // sums of the tensor feeding k
+        __syncthreads();
+        // X = S (branch 0) or S^T (branch 1);  Y[k][j] = Wk[j][k]  (Wk^T)
+        X[i][j] = br ? S[j * ATT_C + i] : S[i * ATT_C + j];
+        Y[i][j] = Wm(mk, j, i);
+        Z[i][j] = Wm(mq, i, j);
+        if (i == 0) {
+            double u = 0, t = 0;
+            for (int k = 0; k < ATT_C; ++k) { u += Wm(mq, j, k) * sq[k]; t += Wm(mk, j, k) * sk[k]; }
+            va[j] = u;   // (Wq sq)[j]
+            vb[j] = t;   // (Wk sk)[j]
+        }
+        __syncthreads();
+        const double t1 = mm(Z, X, i, j);          // (Wq S)[i][j]
+        __syncthreads();
+        Z[i][j] = t1;
+        __syncthreads();
+        double g = mm(Z, Y, i, j);                 // Wq S Wk^T
+        g += va[i] * Bv(mk, j) + Bv(mq, i) * vb[j] + (double)L * Bv(mq, i) * Bv(mk, j);
+        g *= scale;
+        // row softmax over j
+        __syncthreads();
+        X[i][j] = g;
+        __syncthreads();
+        if (j == 0) {
+            double m = X[i][0];
+            for (int k = 1; k < ATT_C; ++k) m = fmax(m, X[i][k]);
+            rowred[i] = m;
+        }
+        __syncthreads();
+        const double e = exp(g - rowred[i]);
+        __syncthreads();
+        X[i][j] = e;
+        __syncthreads();
+        if (j == 0) {
+            double s = 0;
+            for (int k = 0; k < ATT_C; ++k) s += X[i][k];
+            rowred[i] = s;
+        }
+        __syncthreads();
+        const double pr = e / rowred[i];
+        __syncthreads();
+        X[i][j] = pr;                              // attn
+        Y[i][j] = Wm(mv, i, j);                    // Wv
+        Z[i][j] = Wm(mo, i, j);                    // Wo
+        __syncthreads();
+        const double pv = mm(X, Y, i, j);          // attn Wv
+        if (j == 0) {
+            double s = 0;
+            for (int k = 0; k < ATT_C; ++k) s += X[i][k] * Bv(mv, k);
+            va[i] = s;                             // attn bv
+        }
+        __syncthreads();
+        Y[i][j] = pv;
+        __syncthreads();
+        const double mres = mm(Z, Y, i, j);        // Wo attn Wv
+        if (j == 0) {
+            double s = Bv(mo, i);
+            for (int k = 0; k < ATT_C; ++k) s += Z[i][k] * va[k];
+            (br ? c2 : c1)[i] = s;                 // Wo attn bv + bo
+        }
+        (br ? M2 : M1)[i][j] = mres;
+    }
+    __syncthreads();
+    // fused = (Wfa + Wfb M2) F1 + (Wfa M1 + Wfb) F2 + (Wfa c1 + Wfb c2 + bf)
+    X[i][j] = (double)fw[i * 64 + j];        // Wfa
+    Y[i][j] = (double)fw[i * 64 + 32 + j];   // Wfb
+    __syncthreads();
+    const double left = X[i][j] + mm(Y, M2, i, j);
+    const double right = mm(X, M1, i, j) + Y[i][j];
+    // packed layout for bem_pw_gemm (M = 32 -> one M-tile, K = 64 -> KS = 32):
+    //   Wp[st*64 + lane] = W[lane & 31][2*st + (lane >> 5)]
+    float* wp = Wp + (int64_t)b * (32 * 64);
+    {
+        int col = j;            // column of F1 block
+        wp[(col >> 1) * 64 + (col & 1) * 32 + i] = (float)left;
+        col = 32 + j;           // column of F2 block
+        wp[(col >> 1) * 64 + (col & 1) * 32 + i] = (float)right;
+    }
+    if (j == 0) {
+        double s = (double)fb[i];
+        for (int k = 0; k < ATT_C; ++k) s += X[i][k] * c1[k] + Y[i][k] * c2[k];
+        bias_out[(int64_t)b * 32 + i] = (float)s;
+    }
+}
+
+// ---------------------------------------------------------------- layout helpers ------------
+__global__ __launch_bounds__(256) void transpose_planes_kernel(const float* __restrict__ src, int64_t src_bs,
+                                                               float* __restrict__ dst, int64_t dst_bs, int ppb,
+                                                               int H, int W) {
+    __shared__ float t[32][33];
+    const int plane = blockIdx.z;
+    const int bq = plane / ppb, pq = plane - bq * ppb;
+    const int64_t HW = (int64_t)H * W;
+    const float* s = src + (int64_t)bq * src_bs + (int64_t)pq * HW;
+    float* d = dst + (int64_t)bq * dst_bs + (int64_t)pq * HW;
+    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+        const int y = y0 + ty + k, x = x0 + tx;
+        if (y < H && x < W) t[ty + k][tx] = s[(int64_t)y * W + x];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+        const int x = x0 + ty + k, y = y0 + tx;    // dst is (W, H): row x, column y
+        if (x < W && y < H) d[(int64_t)x * H + y] = t[tx][ty + k];
+    }
+}
+
+__global__ void copy_channels_kernel(const float* __restrict__ src, int64_t src_bs, float* __restrict__ dst,
+                                     int64_t dst_bs, int64_t CL, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t b = i / CL, r = i - b * CL;
+    dst[b * dst_bs + r] = src[b * src_bs + r];
+}
+
+__global__ void bilinear_up_kernel(const float* __restrict__ src, int64_t src_bs, float* __restrict__ dst,
+                                   int64_t dst_bs, int C, int H, int W, int s, int64_t total) {
+    // PyTorch upsample_bilinear2d, align_corners=False, scale_factor given: src = (dst + 0.5)/s - 0.5 clamped at 0
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int Wo = W * s, Ho = H * s;
+    const int xo = (int)(i % Wo), yo = (int)((i / Wo) % Ho);
+    const int c = (int)((i / ((int64_t)Wo * Ho)) % C), b = (int)(i / ((int64_t)Wo * Ho * C));
+    const float rs = 1.f / (float)s;
+    float sy = ((float)yo + 0.5f) * rs - 0.5f; sy = sy < 0.f ? 0.f : sy;
+    float sx = ((float)xo + 0.5f) * rs - 0.5f; sx = sx < 0.f ? 0.f : sx;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float* p = src + (int64_t)b * src_bs + (int64_t)c * H * W;
+    const float v = hy * (hx * p[(int64_t)y0 * W + x0] + lx * p[(int64_t)y0 * W + x1]) +
+                    ly * (hx * p[(int64_t)y1 * W + x0] + lx * p[(int64_t)y1 * W + x1]);
+    dst[(int64_t)b * dst_bs + ((int64_t)c * Ho + yo) * Wo + xo] = v;
+}
+
+__global__ void space_to_depth_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int H, int W,
+                                      int64_t total) {
+    // out (B,4C,H/2,W/2): block q = dy + 2*dx  ->  [ee, oe, eo, oo]  (UNet_arch.py:74-78)
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int h2 = H >> 1, w2 = W >> 1;
+    const int xx = (int)(i % w2), y = (int)((i / w2) % h2);
+    const int cc = (int)((i / ((int64_t)w2 * h2)) % (4 * C)), b = (int)(i / ((int64_t)w2 * h2 * 4 * C));
+    const int q = cc / C, c = cc - q * C;
+    const int dy = q & 1, dx = q >> 1;
+    out[i] = x[(((int64_t)b * C + c) * H + 2 * y + dy) * W + 2 * xx + dx];
+}
+
+__global__ void pixel_shuffle2_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int H, int W,
+                                      int64_t total) {
+    // out (B,C,2H,2W)[c][2y+i][2x+j] = x[c*4 + i*2 + j][y][x]
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int Wo = 2 * W, Ho = 2 * H;
+    const int xo = (int)(i % Wo), yo = (int)((i / Wo) % Ho);
+    const int c = (int)((i / ((int64_t)Wo * Ho)) % C), b = (int)(i / ((int64_t)Wo * Ho * C));
+    const int ch = c * 4 + (yo & 1) * 2 + (xo & 1);
+    out[i] = x[(((int64_t)b * 4 * C + ch) * H + (yo >> 1)) * W + (xo >> 1)];
+}
+
+// ---------------------------------------------------------------- Bayesian sampling ----------
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+__global__ void bnn_sample_kernel(const float* __restrict__ mu, const float* __restrict__ rho,
+                                  const float* __restrict__ eps_in, float* __restrict__ out, int64_t n, int64_t total,
+                                  uint64_t seed, uint64_t stream_id) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t e = i % n;
+    float eps;
+    if (eps_in) {
+        eps = eps_in[i];
+    } else {
+        uint32_t c[4] = {(uint32_t)i, (uint32_t)((uint64_t)i >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
+        philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        const float u1 = ((float)(c[0] >> 8) + 1.0f) * (1.0f / 16777216.0f);   // (0, 1]
+        const float u2 = (float)(c[1] >> 8) * (1.0f / 16777216.0f);            // [0, 1)
+        eps = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);    // Box-Muller
+    }
+    out[i] = mu[e] + log1pf(expf(rho[e])) * eps;
+}
+
+// ---------------------------------------------------------------- Monte-Carlo loop pieces ----
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    double s = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += sh[w];
+    return s;
+}
+
+__global__ __launch_bounds__(256) void plane_mean_kernel(const float* __restrict__ x, float* __restrict__ means,
+                                                         int Hs, int Ws, int h, int w) {
+    __shared__ double sh[4];
+    const float* p = x + (int64_t)blockIdx.x * Hs * Ws;
+    double s = 0;
+    for (int i = threadIdx.x; i < h * w; i += 256) s += (double)p[(int64_t)(i / w) * Ws + (i % w)];
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) means[blockIdx.x] = (float)(s / ((double)h * w));
+}
+
+__global__ __launch_bounds__(256) void cond_postproc_kernel(const float* __restrict__ pred,
+                                                            const float* __restrict__ target_mean,
+                                                            const float* __restrict__ noise, float* __restrict__ out,
+                                                            int hw, int spi, float noise_level) {
+    // one workgroup per (sample, channel) plane
+    __shared__ double sh[4];
+    const int plane = blockIdx.x, bn = plane / 3, ch = plane - bn * 3;
+    const float* p = pred + (int64_t)plane * hw;
+    float ratio = 1.f;
+    if (target_mean) {
+        double s = 0;
+        for (int i = threadIdx.x; i < hw; i += 256) s += (double)fminf(fmaxf(p[i], 0.f), 1.f);
+        s = block_sum(s, sh);
+        const float mean_pred = (float)(s / (double)hw);
+        ratio = target_mean[(bn / spi) * 3 + ch] / mean_pred;
+    }
+    for (int i = threadIdx.x; i < hw; i += 256) {
+        float c = fminf(fmaxf(p[i], 0.f), 1.f);
+        if (target_mean) c = fminf(fmaxf(c * ratio, 0.f), 1.f);
+        if (noise) c += noise[(int64_t)plane * hw + i] * noise_level;
+        out[(int64_t)plane * hw + i] = c;
+    }
+}
+
+__global__ __launch_bounds__(256) void candidate_finalize_kernel(const float* __restrict__ pred,
+                                                                 const float* __restrict__ target,
+                                                                 float* __restrict__ fin, float* __restrict__ psnr,
+                                                                 int spi, int Hp, int Wp, int h, int w, int gt_mean) {
+    // one workgroup per candidate
+    __shared__ double sh[4];
+    const int bn = blockIdx.x;
+    const int64_t hw = (int64_t)h * w;
+    const float* tg = target ? target + (int64_t)(bn / spi) * 3 * hw : nullptr;
+    double mse = 0;
+    for (int ch = 0; ch < 3; ++ch) {
+        const float* p = pred + ((int64_t)bn * 3 + ch) * Hp * Wp;
+        float ratio = 1.f;
+        if (gt_mean) {
+            double sp = 0, st = 0;
+            for (int i = threadIdx.x; i < hw; i += 256) {
+                sp += (double)fminf(fmaxf(p[(int64_t)(i / w) * Wp + (i % w)], 0.f), 1.f);
+                st += (double)tg[(int64_t)ch * hw + i];
+            }
+            sp = block_sum(sp, sh);
+            st = block_sum(st, sh);
+            ratio = (float)(st / (double)hw) / (float)(sp / (double)hw);
+        }
+        for (int i = threadIdx.x; i < hw; i += 256) {
+            float v = fminf(fmaxf(p[(int64_t)(i / w) * Wp + (i % w)], 0.f), 1.f);
+            if (gt_mean) v = fminf(fmaxf(v * ratio, 0.f), 1.f);
+            fin[((int64_t)bn * 3 + ch) * hw + i] = v;
+            if (tg) {
+                const double d = (double)tg[(int64_t)ch * hw + i] - (double)v;
+                mse += d * d;
+            }
+        }
+    }
+    mse = block_sum(mse, sh);
+    if (threadIdx.x == 0 && psnr) {
+        const double m = mse / (3.0 * (double)hw);
+        psnr[bn] = tg ? (m == 0 ? 100.f : (float)(10.0 * log10(1.0 / m))) : 0.f;
+    }
+}
+
+}  // namespace
+
+// ================================================================ C ABI =========================
+extern "C" int bem_quat_dwt_f32(const float* rgb, int64_t x_bstride, float* out, int B, int H, int W, void* stream) {
+    BEM_REQUIRE(rgb && out, "quat_dwt: null tensor");
+    BEM_REQUIRE(B >= 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "quat_dwt: H, W must be even (got %d x %d)", H, W);
+    if (B == 0) return BEM_OK;
+    const int64_t total = (int64_t)B * (H / 2) * (W / 2);
+    quat_dwt_kernel<<<GRID1D(total), 256, 0, (hipStream_t)stream>>>(rgb, x_bstride, out, H, W, total);
+    return bem_check_launch("quat_dwt");
+}
+
+extern "C" int bem_dwt_f32(const float* x, float* out, int B, int C, int H, int W, void* stream) {
+    BEM_REQUIRE(x && out, "dwt: null tensor");
+    BEM_REQUIRE(B >= 0 && C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "dwt: H, W must be even");
+    if (B == 0) return BEM_OK;
+    const int64_t total = (int64_t)B * C * (H / 2) * (W / 2);
+    dwt_kernel<<<GRID1D(total), 256, 0, (hipStream_t)stream>>>(x, out, C, H, W, total);
+    return bem_check_launch("dwt");
+}
+
+extern "C" int bem_iwt_f32(const float* x, float* out, int B, int C4, int H, int W, void* stream) {
+    BEM_REQUIRE(x && out, "iwt: null tensor");
+    BEM_REQUIRE(B >= 0 && C4 > 0 && C4 % 4 == 0 && H > 0 && W > 0, "iwt: channels %d must be a multiple of 4", C4);
+    if (B == 0) return BEM_OK;
+    const int64_t total = (int64_t)B * (C4 / 4) * H * W;
+    iwt_kernel<<<GRID1D(total), 256, 0, (hipStream_t)stream>>>(x, out, C4 / 4, H, W, total);
+    return bem_check_launch("iwt");
+}
+
+extern "C" int bem_iwt_hamilton_f32(const float* q1w, const float* q2w, float* out, int B, int h, int w, void* stream) {
+    BEM_REQUIRE(q1w && q2w && out, "iwt_hamilton: null tensor");
+    BEM_REQUIRE(B >= 0 && h > 0 && w > 0, "iwt_hamilton: bad shape");
+    if (B == 0) return BEM_OK;
+    const int64_t total = (int64_t)B * h * w;
+    iwt_hamilton_kernel<<<GRID1D(total), 256, 0, (hipStream_t)stream>>>(q1w, q2w, out, h, w, total);
+    return bem_check_launch("iwt_hamilton");
+}
+
+extern "C" int bem_hamilton_f32(const float* q, float* out, int B, int H, int W, void* stream) {
+    BEM_REQUIRE(q && out, "hamilton: null tensor");
+    BEM_REQUIRE(B >= 0 && H > 0 && W > 0, "hamilton: bad shape");
+    if (B == 0) return BEM_OK;
+    const int64_t total = (int64_t)B * H * W;
+    hamilton_kernel<<<GRID1D(total), 256, 0, (hipStream_t)stream>>>(q, out, (int64_t)H * W, total);
+    return bem_check_launch("hamilton");
+}
+
+extern "C" int bem_attn_stats_f64(const float* f1, const float* f2, double* stats, int B, int L, void* stream) {
+    BEM_REQUIRE(f1 && f2 && stats, "attn_stats: null tensor");
+    BEM_REQUIRE(B >= 0 && B <= 65535 && L > 0, "attn_stats: bad shape");
+    if (B == 0) return BEM_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(stats, 0, sizeof(double) * (size_t)B * (ATT_C * ATT_C + 2 * ATT_C), s) != hipSuccess)
+        return bem_check_launch("attn_stats memset");
+    dim3 grid(cdiv(L, ATT_CHUNK), B);
+    attn_stats_kernel<<<grid, 256, 0, s>>>(f1, f2, stats, L);
+    return bem_check_launch("attn_stats");
+}
+
+extern "C" int bem_attn_fold_f32(const double* stats, const float* attn_w, const float* fuse_w, const float* fuse_b,
+                                 float* Wp_out, float* bias_out, int B, int L, void* stream) {
+    BEM_REQUIRE(stats && attn_w && fuse_w && fuse_b && Wp_out && bias_out, "attn_fold: null tensor");
+    BEM_REQUIRE(B >= 0 && L > 0, "attn_fold: bad shape");
+    if (B == 0) return BEM_OK;
+    attn_fold_kernel<<<B, 1024, 0, (hipStream_t)stream>>>(stats, attn_w, fuse_w, fuse_b, Wp_out, bias_out, L);
+    return bem_check_launch("attn_fold");
+}
+
+extern "C" int bem_transpose_planes_f32(const float* src, int64_t src_bstride, float* dst, int64_t dst_bstride,
+                                        int nbatch, int ppb, int H, int W, void* stream) {
+    BEM_REQUIRE(src && dst, "transpose_planes: null tensor");
+    BEM_REQUIRE(nbatch >= 0 && ppb > 0 && H > 0 && W > 0, "transpose_planes: bad shape");
+    BEM_REQUIRE((int64_t)nbatch * ppb <= 65535 && cdiv(H, 32) <= 65535, "transpose_planes: too many planes (%lld)", (long long)nbatch * ppb);
+    if (nbatch == 0) return BEM_OK;
+    dim3 grid(cdiv(W, 32), cdiv(H, 32), nbatch * ppb);
+    transpose_planes_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(src, src_bstride, dst, dst_bstride, ppb, H, W);
+    return bem_check_launch("transpose_planes");
+}
+
+extern "C" int bem_copy_channels_f32(const float* src, int64_t src_bstride, float* dst, int64_t dst_bstride, int B,
+                                     int C, int L, void* stream) {
+    BEM_REQUIRE(src && dst, "copy_channels: null tensor");
+    BEM_REQUIRE(B >= 0 && C > 0 && L >= 0, "copy_channels: bad shape");
+    const int64_t total = (int64_t)B * C * L;
+    if (total == 0) return BEM_OK;
+    copy_channels_kernel<<<GRID1D(total), 256, 0, (hipStream_t)stream>>>(src, src_bstride, dst, dst_bstride, (int64_t)C * L, total);
+    return bem_check_launch("copy_channels");
+}
+
+extern "C" int bem_bilinear_up_f32(const float* src, int64_t src_bstride, float* dst, int64_t dst_bstride, int B, int C,
+                                   int H, int W, int s, void* stream) {
+    BEM_REQUIRE(src && dst, "bilinear_up: null tensor");
+    BEM_REQUIRE(B >= 0 && C > 0 && H > 0 && W > 0 && s >= 1, "bilinear_up: bad shape");
+    const int64_t total = (int64_t)B * C * H * W * s * s;
+    if (total == 0) return BEM_OK;
+    bilinear_up_kernel<<<GRID1D(total), 256, 0, (hipStream_t)stream>>>(src, src_bstride, dst, dst_bstride, C, H, W, s, total);
+    return bem_check_launch("bilinear_up");
+}
+
+extern "C" int bem_space_to_depth_f32(const float* x, float* out, int B, int C, int H, int W, void* stream) {
+    BEM_REQUIRE(x && out, "space_to_depth: null tensor");
+    BEM_REQUIRE(B >= 0 && C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "space_to_depth: H, W must be even");
+    const int64_t total = (int64_t)B * C * H * W;
+    if (total == 0) return BEM_OK;
+    space_to_depth_kernel<<<GRID1D(total), 256, 0, (hipStream_t)stream>>>(x, out, C, H, W, total);
+    return bem_check_launch("space_to_depth");
+}
+
+extern "C" int bem_pixel_shuffle2_f32(const float* x, float* out, int B, int C, int H, int W, void* stream) {
+    BEM_REQUIRE(x && out, "pixel_shuffle2: null tensor");
+    BEM_REQUIRE(B >= 0 && C > 0 && H > 0 && W > 0, "pixel_shuffle2: bad shape");
+    const int64_t total = (int64_t)B * C * H * W * 4;
+    if (total == 0) return BEM_OK;
+    pixel_shuffle2_kernel<<<GRID1D(total), 256, 0, (hipStream_t)stream>>>(x, out, C, H, W, total);
+    return bem_check_launch("pixel_shuffle2");
+}
+
+extern "C" int bem_bnn_sample_f32(const float* mu, const float* rho, const float* eps_in, float* out, int nsets,
+                                  int64_t n, uint64_t seed, uint64_t stream_id, void* stream) {
+    BEM_REQUIRE(mu && rho && out, "bnn_sample: null tensor");
+    BEM_REQUIRE(nsets >= 0 && n >= 0, "bnn_sample: bad shape");
+    const int64_t total = (int64_t)nsets * n;
+    if (total == 0) return BEM_OK;
+    bnn_sample_kernel<<<GRID1D(total), 256, 0, (hipStream_t)stream>>>(mu, rho, eps_in, out, n, total, seed, stream_id);
+    return bem_check_launch("bnn_sample");
+}
+
+extern "C" int bem_cond_postproc_f32(const float* pred, const float* target_mean, const float* noise, float* out,
+                                     int Bn, int h, int w, int samples_per_image, float noise_level, void* stream) {
+    BEM_REQUIRE(pred && out, "cond_postproc: null tensor");
+    BEM_REQUIRE(Bn >= 0 && h > 0 && w > 0 && samples_per_image >= 1, "cond_postproc: bad shape");
+    if (Bn == 0) return BEM_OK;
+    cond_postproc_kernel<<<Bn * 3, 256, 0, (hipStream_t)stream>>>(pred, target_mean, noise, out, h * w, samples_per_image, noise_level);
+    return bem_check_launch("cond_postproc");
+}
+
+extern "C" int bem_plane_mean_f32(const float* x, float* means, int P, int Hs, int Ws, int h, int w, void* stream) {
+    BEM_REQUIRE(x && means, "plane_mean: null tensor");
+    BEM_REQUIRE(P >= 0 && h > 0 && w > 0 && h <= Hs && w <= Ws, "plane_mean: bad shape");
+    if (P == 0) return BEM_OK;
+    plane_mean_kernel<<<P, 256, 0, (hipStream_t)stream>>>(x, means, Hs, Ws, h, w);
+    return bem_check_launch("plane_mean");
+}
+
+extern "C" int bem_candidate_finalize_f32(const float* pred, const float* target, float* final_out, float* psnr,
+                                          int Bn, int samples_per_image, int Hp, int Wp, int h, int w, int gt_mean,
+                                          void* stream) {
+    BEM_REQUIRE(pred && final_out, "candidate_finalize: null tensor");
+    BEM_REQUIRE(Bn >= 0 && samples_per_image >= 1 && h > 0 && w > 0 && h <= Hp && w <= Wp, "candidate_finalize: bad shape");
+    BEM_REQUIRE(!gt_mean || target, "candidate_finalize: GT_mean needs a target");
+    if (Bn == 0) return BEM_OK;
+    candidate_finalize_kernel<<<Bn, 256, 0, (hipStream_t)stream>>>(pred, target, final_out, psnr, samples_per_image, Hp, Wp, h, w, gt_mean);
+    return bem_check_launch("candidate_finalize");
+}

@@ -1,0 +1,334 @@
+// Selective scan kernels for CDNA4 (wave64).
+//   - bem_selective_scan_fwd_f32 : operator-seam replacement of selective_scan_cuda_oflex.fwd
+//   - bem_ss2d_scan_f32          : fused x_proj-rows -> dt_proj -> softplus -> 4-direction scan (N = 1)
+//   - bem_cross_scan / merge     : operator-seam replacements of the Triton cross scan / merge
+//
+// Scan structure: every thread owns E consecutive sequence positions, folds them into an affine map
+// h -> P*h + S, the 64 lanes of a wave compose their maps with wavefront shuffles (Hillis-Steele,
+// 6 steps), waves exchange their aggregates through LDS and a running carry links successive chunks.
+// The reverse directions use the mirrored lane / wave / element order of the same code.
+#include "bem_common.h"
+
+namespace {
+
+template <bool REV>
+__device__ __forceinline__ float shfl_prev(float v, int d) {
+    return REV ? __shfl_down(v, d, BEM_WAVE) : __shfl_up(v, d, BEM_WAVE);
+}
+
+// Block-wide composition of per-thread affine maps.  On entry (a[e], b[e]) are the per-position
+// coefficients h_t = a_t * h_prev + b_t of this thread's E positions (identity = (1, 0) for padding).
+// On exit h[e] holds the state after position e; `carry` (state entering the chunk, uniform) is updated
+// to the state leaving the chunk.  agg is LDS scratch of 2*NW floats; contains two barriers.
+template <int NT, int E, bool REV>
+__device__ __forceinline__ void block_scan_affine(const float (&a)[E], const float (&b)[E], float (&h)[E],
+                                                  float& carry, float* agg) {
+    constexpr int NW = NT / BEM_WAVE;
+    const int lane = threadIdx.x & (BEM_WAVE - 1);
+    const int wave = threadIdx.x / BEM_WAVE;
+    const int rl = REV ? (BEM_WAVE - 1 - lane) : lane;   // logical lane in scan order
+    float P = 1.f, S = 0.f;
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        const int e = REV ? (E - 1 - i) : i;
+        S = a[e] * S + b[e];
+        P = P * a[e];
+    }
+    // inclusive wave scan of (P, S): compose(prev, cur) = (Pp*Pc, Pc*Sp + Sc)
+#pragma unroll
+    for (int d = 1; d < BEM_WAVE; d <<= 1) {
+        const float Pp = shfl_prev<REV>(P, d);
+        const float Sp = shfl_prev<REV>(S, d);
+        if (rl >= d) {
+            S = P * Sp + S;
+            P = P * Pp;
+        }
+    }
+    float Pe = shfl_prev<REV>(P, 1);
+    float Se = shfl_prev<REV>(S, 1);
+    if (rl == 0) { Pe = 1.f; Se = 0.f; }
+    if (NW > 1) {
+        if (rl == BEM_WAVE - 1) { agg[2 * wave] = P; agg[2 * wave + 1] = S; }
+        __syncthreads();
+    }
+    float hw = carry;      // state entering this wave
+    float hend = carry;    // state leaving the chunk
+    if (NW > 1) {
+        const int rw = REV ? (NW - 1 - wave) : wave;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int w = REV ? (NW - 1 - i) : i;
+            const float Pw = agg[2 * w], Sw = agg[2 * w + 1];
+            hend = Pw * hend + Sw;
+            if (i < rw) hw = Pw * hw + Sw;
+        }
+        __syncthreads();   // agg may be rewritten by the next call
+    } else {
+        // single wave: total = inclusive value of the last logical lane
+        const float Pt = __shfl(P, REV ? 0 : BEM_WAVE - 1, BEM_WAVE);
+        const float St = __shfl(S, REV ? 0 : BEM_WAVE - 1, BEM_WAVE);
+        hend = Pt * carry + St;
+    }
+    float hh = Pe * hw + Se;   // state entering this thread
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        const int e = REV ? (E - 1 - i) : i;
+        hh = a[e] * hh + b[e];
+        h[e] = hh;
+    }
+    carry = hend;
+}
+
+template <int E>
+__device__ __forceinline__ void load_row(const float* __restrict__ p, int64_t t0, int L, bool vec, float (&v)[E]) {
+    if (vec && t0 + E <= L) {
+#pragma unroll
+        for (int i = 0; i < E; i += 4) {
+            const float4 q = *reinterpret_cast<const float4*>(p + t0 + i);
+            v[i] = q.x; v[i + 1] = q.y; v[i + 2] = q.z; v[i + 3] = q.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < E; ++i) v[i] = (t0 + i < L) ? p[t0 + i] : 0.f;
+    }
+}
+template <int E>
+__device__ __forceinline__ void store_row(float* __restrict__ p, int64_t t0, int L, bool vec, const float (&v)[E]) {
+    if (vec && t0 + E <= L) {
+#pragma unroll
+        for (int i = 0; i < E; i += 4)
+            *reinterpret_cast<float4*>(p + t0 + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < E; ++i)
+            if (t0 + i < L) p[t0 + i] = v[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// General selective scan (any dstate, groups): one workgroup per (batch, channel) row.
+// ------------------------------------------------------------------------------------------------
+template <int NT, int E>
+__global__ __launch_bounds__(NT) void selective_scan_fwd_kernel(
+    const float* __restrict__ u, const float* __restrict__ delta, const float* __restrict__ A,
+    const float* __restrict__ Bm, const float* __restrict__ Cm, const float* __restrict__ D,
+    const float* __restrict__ dbias, float* __restrict__ out, int dim, int L, int dstate, int ngroups,
+    int softplus) {
+    __shared__ float agg[2 * (NT / BEM_WAVE)];
+    __shared__ float carry_s[256];
+    const int d = blockIdx.x, b = blockIdx.y;
+    const int g = d / (dim / ngroups);
+    const int64_t row = ((int64_t)b * dim + d) * L;
+    const float* ur = u + row;
+    const float* dr = delta + row;
+    float* yr = out + row;
+    const float bias = dbias ? dbias[d] : 0.f;
+    const float Dd = D ? D[d] : 0.f;
+    const bool vec = (L % 4 == 0);
+    for (int n = threadIdx.x; n < dstate; n += NT) carry_s[n] = 0.f;
+    __syncthreads();
+    constexpr int CH = NT * E;
+    for (int64_t c0 = 0; c0 < L; c0 += CH) {
+        const int64_t t0 = c0 + (int64_t)threadIdx.x * E;
+        float uu[E], dt[E], y[E];
+        load_row<E>(ur, t0, L, vec, uu);
+        load_row<E>(dr, t0, L, vec, dt);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            dt[e] += bias;
+            if (softplus) dt[e] = bem_softplus(dt[e]);
+            y[e] = Dd * uu[e];
+        }
+        for (int n = 0; n < dstate; ++n) {
+            const float An = A[(int64_t)d * dstate + n];
+            const int64_t bc = (((int64_t)b * ngroups + g) * dstate + n) * L;
+            float Bv[E], Cv[E], a[E], bb[E], h[E];
+            load_row<E>(Bm + bc, t0, L, vec, Bv);
+            load_row<E>(Cm + bc, t0, L, vec, Cv);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const bool ok = t0 + e < L;
+                a[e] = ok ? expf(dt[e] * An) : 1.f;
+                bb[e] = ok ? dt[e] * Bv[e] * uu[e] : 0.f;
+            }
+            float carry = carry_s[n];
+            block_scan_affine<NT, E, false>(a, bb, h, carry, agg);
+            if (threadIdx.x == 0) carry_s[n] = carry;
+#pragma unroll
+            for (int e = 0; e < E; ++e) y[e] += Cv[e] * h[e];
+        }
+        store_row<E>(yr, t0, L, vec, y);
+        __syncthreads();   // carry_s visible to all threads before the next chunk
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused SS2D scan (N = 1): grid (C, B, 2 orientations).  Each workgroup owns one (b, c) sequence of
+// one orientation and runs its forward direction (k = o) and reverse direction (k = o + 2).
+// ------------------------------------------------------------------------------------------------
+template <int E>
+__device__ __forceinline__ void ss2d_coeffs(const float* __restrict__ xd /* (R+2, L) of one direction */,
+                                            const float* __restrict__ wdt /* (R) */, float dtb, float Ak,
+                                            const float (&x)[E], int64_t t0, int L, int R, bool vec,
+                                            float (&a)[E], float (&b)[E], float (&cv)[E]) {
+    float dt[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) dt[e] = 0.f;
+    for (int r = 0; r < R; ++r) {
+        float v[E];
+        load_row<E>(xd + (int64_t)r * L, t0, L, vec, v);
+        const float w = wdt[r];
+#pragma unroll
+        for (int e = 0; e < E; ++e) dt[e] = fmaf(w, v[e], dt[e]);
+    }
+    float Bv[E];
+    load_row<E>(xd + (int64_t)R * L, t0, L, vec, Bv);
+    load_row<E>(xd + (int64_t)(R + 1) * L, t0, L, vec, cv);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const bool ok = t0 + e < L;
+        const float dl = bem_softplus(dt[e] + dtb);
+        a[e] = ok ? expf(dl * Ak) : 1.f;
+        b[e] = ok ? dl * Bv[e] * x[e] : 0.f;
+    }
+}
+
+template <int NT, int E>
+__global__ __launch_bounds__(NT) void ss2d_scan_kernel(
+    const float* __restrict__ x0, const float* __restrict__ x1, const float* __restrict__ xd0,
+    const float* __restrict__ xd1, const float* __restrict__ dtw, const float* __restrict__ dtb,
+    const float* __restrict__ A, const float* __restrict__ Ds, float* __restrict__ y0,
+    float* __restrict__ y1, int C, int L, int R) {
+    __shared__ float agg[2 * (NT / BEM_WAVE)];
+    const int c = blockIdx.x, b = blockIdx.y, o = blockIdx.z;
+    const float* xr = (o ? x1 : x0) + ((int64_t)b * C + c) * L;
+    const float* xd = (o ? xd1 : xd0) + (int64_t)b * 2 * (R + 2) * L;
+    float* yr = (o ? y1 : y0) + ((int64_t)b * C + c) * L;
+    const int kf = o, kr = o + 2;
+    const float* wf = dtw + ((int64_t)kf * C + c) * R;
+    const float* wr = dtw + ((int64_t)kr * C + c) * R;
+    const float bf = dtb[kf * C + c], br = dtb[kr * C + c];
+    const float Af = A[kf * C + c], Ar = A[kr * C + c];
+    const float Df = Ds[kf * C + c], Dr = Ds[kr * C + c];
+    const bool vec = (L % 4 == 0);
+    constexpr int CH = NT * E;
+    const int nchunks = (L + CH - 1) / CH;
+    const bool single = nchunks == 1;
+    float yacc[E];
+    // forward direction, chunks ascending
+    float carry = 0.f;
+    for (int j = 0; j < nchunks; ++j) {
+        const int64_t t0 = (int64_t)j * CH + (int64_t)threadIdx.x * E;
+        float x[E], a[E], bb[E], cv[E], h[E];
+        load_row<E>(xr, t0, L, vec, x);
+        ss2d_coeffs<E>(xd, wf, bf, Af, x, t0, L, R, vec, a, bb, cv);
+        block_scan_affine<NT, E, false>(a, bb, h, carry, agg);
+#pragma unroll
+        for (int e = 0; e < E; ++e) yacc[e] = fmaf(cv[e], h[e], Df * x[e]);
+        if (!single) store_row<E>(yr, t0, L, vec, yacc);
+    }
+    // reverse direction, chunks descending; adds onto the forward result
+    carry = 0.f;
+    for (int j = nchunks - 1; j >= 0; --j) {
+        const int64_t t0 = (int64_t)j * CH + (int64_t)threadIdx.x * E;
+        float x[E], a[E], bb[E], cv[E], h[E], yv[E];
+        load_row<E>(xr, t0, L, vec, x);
+        ss2d_coeffs<E>(xd + (int64_t)(R + 2) * L, wr, br, Ar, x, t0, L, R, vec, a, bb, cv);
+        block_scan_affine<NT, E, true>(a, bb, h, carry, agg);
+        if (!single) load_row<E>(yr, t0, L, vec, yacc);   // this thread's own earlier stores
+#pragma unroll
+        for (int e = 0; e < E; ++e) yv[e] = yacc[e] + fmaf(cv[e], h[e], Dr * x[e]);
+        store_row<E>(yr, t0, L, vec, yv);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// cross scan / merge (operator seam only; the fused path never materialises the 4x tensor)
+// ------------------------------------------------------------------------------------------------
+__global__ void cross_scan_kernel(const float* __restrict__ x, float* __restrict__ xs, int C, int H, int W) {
+    // grid: (ceil(L/256), C, B); xs (B,4,C,L)
+    const int L = H * W;
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= L) return;
+    const int c = blockIdx.y, b = blockIdx.z;
+    const float* xp = x + ((int64_t)b * C + c) * L;
+    float* o = xs + (((int64_t)b * 4) * C + c) * L;
+    const int64_t ks = (int64_t)C * L;
+    const float v0 = xp[l];
+    const int wq = l / H, hq = l % H;            // column-major index l -> pixel (hq, wq)
+    const float v1 = xp[hq * W + wq];
+    o[l] = v0;
+    o[ks + l] = v1;
+    o[2 * ks + (L - 1 - l)] = v0;
+    o[3 * ks + (L - 1 - l)] = v1;
+}
+
+__global__ void cross_merge_kernel(const float* __restrict__ ys, float* __restrict__ y, int C, int H, int W) {
+    const int L = H * W;
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= L) return;
+    const int c = blockIdx.y, b = blockIdx.z;
+    const float* p = ys + (((int64_t)b * 4) * C + c) * L;
+    const int64_t ks = (int64_t)C * L;
+    const int h = l / W, w = l % W;
+    const int lc = w * H + h;
+    y[((int64_t)b * C + c) * L + l] = (p[l] + p[2 * ks + (L - 1 - l)]) + (p[ks + lc] + p[3 * ks + (L - 1 - lc)]);
+}
+
+}  // namespace
+
+extern "C" int bem_selective_scan_fwd_f32(const float* u, const float* delta, const float* A, const float* Bm,
+                                          const float* Cm, const float* D, const float* delta_bias, float* out,
+                                          int batch, int dim, int L, int dstate, int ngroups, int delta_softplus,
+                                          void* stream) {
+    BEM_REQUIRE(u && delta && A && Bm && Cm && out, "selective_scan_fwd: null tensor");
+    BEM_REQUIRE(batch >= 0 && dim > 0 && L >= 0, "selective_scan_fwd: bad shape (%d,%d,%d)", batch, dim, L);
+    BEM_REQUIRE(dstate >= 1 && dstate <= 256, "selective_scan_fwd: dstate %d not in [1,256]", dstate);
+    BEM_REQUIRE(ngroups >= 1 && dim % ngroups == 0, "selective_scan_fwd: dim %d %% ngroups %d != 0", dim, ngroups);
+    BEM_REQUIRE(batch <= 65535, "selective_scan_fwd: batch %d > 65535", batch);
+    if (batch == 0 || L == 0) return BEM_OK;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(dim, batch);
+    if (L <= 256)
+        selective_scan_fwd_kernel<64, 4><<<grid, 64, 0, s>>>(u, delta, A, Bm, Cm, D, delta_bias, out, dim, L, dstate, ngroups, delta_softplus);
+    else if (L <= 1024)
+        selective_scan_fwd_kernel<128, 8><<<grid, 128, 0, s>>>(u, delta, A, Bm, Cm, D, delta_bias, out, dim, L, dstate, ngroups, delta_softplus);
+    else
+        selective_scan_fwd_kernel<256, 8><<<grid, 256, 0, s>>>(u, delta, A, Bm, Cm, D, delta_bias, out, dim, L, dstate, ngroups, delta_softplus);
+    return bem_check_launch("selective_scan_fwd");
+}
+
+extern "C" int bem_ss2d_scan_f32(const float* x0, const float* x1, const float* xd0, const float* xd1,
+                                 const float* dtw, const float* dtb, const float* A, const float* Ds, float* y0,
+                                 float* y1, int B, int C, int L, int R, void* stream) {
+    BEM_REQUIRE(x0 && x1 && xd0 && xd1 && dtw && dtb && A && Ds && y0 && y1, "ss2d_scan: null tensor");
+    BEM_REQUIRE(B >= 0 && B <= 65535 && C > 0 && L >= 0 && R >= 1, "ss2d_scan: bad shape B=%d C=%d L=%d R=%d", B, C, L, R);
+    if (B == 0 || L == 0) return BEM_OK;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(C, B, 2);
+    if (L <= 256)
+        ss2d_scan_kernel<64, 4><<<grid, 64, 0, s>>>(x0, x1, xd0, xd1, dtw, dtb, A, Ds, y0, y1, C, L, R);
+    else if (L <= 1024)
+        ss2d_scan_kernel<128, 8><<<grid, 128, 0, s>>>(x0, x1, xd0, xd1, dtw, dtb, A, Ds, y0, y1, C, L, R);
+    else
+        ss2d_scan_kernel<256, 8><<<grid, 256, 0, s>>>(x0, x1, xd0, xd1, dtw, dtb, A, Ds, y0, y1, C, L, R);
+    return bem_check_launch("ss2d_scan");
+}
+
+extern "C" int bem_cross_scan_f32(const float* x, float* xs, int B, int C, int H, int W, void* stream) {
+    BEM_REQUIRE(x && xs, "cross_scan: null tensor");
+    BEM_REQUIRE(B >= 0 && B <= 65535 && C > 0 && C <= 65535 && H > 0 && W > 0, "cross_scan: bad shape");
+    if (B == 0) return BEM_OK;
+    dim3 grid(cdiv(H * W, 256), C, B);
+    cross_scan_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, xs, C, H, W);
+    return bem_check_launch("cross_scan");
+}
+
+extern "C" int bem_cross_merge_f32(const float* ys, float* y, int B, int C, int H, int W, void* stream) {
+    BEM_REQUIRE(ys && y, "cross_merge: null tensor");
+    BEM_REQUIRE(B >= 0 && B <= 65535 && C > 0 && C <= 65535 && H > 0 && W > 0, "cross_merge: bad shape");
+    if (B == 0) return BEM_OK;
+    dim3 grid(cdiv(H * W, 256), C, B);
+    cross_merge_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(ys, y, C, H, W);
+    return bem_check_launch("cross_merge");
+}

@@ -1,0 +1,179 @@
+/*
+ * bem_hip.h -- C ABI of libbem_hip.so: the MI355X (gfx950) hot path of the Bayesian Enhancement
+ * Model (two-stage N-sample Bayesian low-light enhancement).
+ *
+ * Conventions (all entry points)
+ *   - plain device pointers + sizes, float32, NCHW / (B, C, L) contiguous unless a stride is given;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream),
+ *     no internal synchronisation, no global state, re-entrant across streams -- the same contract
+ *     as the reference's extension (selective_scan_oflex.cpp:232-233);
+ *   - return value 0 = launched, non-zero = rejected (bad shape / null pointer / HIP launch error);
+ *     bem_last_error() gives the message for the calling thread.  Nothing is launched on rejection.
+ *   - "reference" paths below are relative to vfrantc/Bayesian-Enhancement-Model.
+ *
+ * The library has NO CPU path: without a gfx950 device the calls fail (hipErrorNoDevice).
+ */
+#ifndef BEM_HIP_H
+#define BEM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BEM_OK 0
+#define BEM_ERR_INVALID 1
+#define BEM_ERR_LAUNCH 2
+
+const char* bem_last_error(void);
+int bem_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Operator seam: what basicsr/vmamba/models/csms6s.py and csm_triton.py call.
+ * ------------------------------------------------------------------------------------------- */
+
+/* Replaces selective_scan_cuda_oflex.fwd (kernels/selective_scan/csrc/selective_scan/cusoflex/
+ * selective_scan_oflex.cpp:157-243; kernel selective_scan_fwd_kernel_oflex.cuh:67-180), f32 in/out.
+ * u, delta, out: (batch, dim, L); A: (dim, dstate); Bm, Cm: (batch, ngroups, dstate, L);
+ * D, delta_bias: (dim) or NULL.  dim % ngroups == 0, 1 <= dstate <= 256. */
+int bem_selective_scan_fwd_f32(const float* u, const float* delta, const float* A, const float* Bm,
+                               const float* Cm, const float* D, const float* delta_bias, float* out,
+                               int batch, int dim, int L, int dstate, int ngroups, int delta_softplus,
+                               void* stream);
+
+/* Replaces cross_scan_fn / triton_cross_scan_flex (csm_triton.py:278-423): x (B,C,H,W) -> xs (B,4,C,H*W). */
+int bem_cross_scan_f32(const float* x, float* xs, int B, int C, int H, int W, void* stream);
+/* Replaces cross_merge_fn (csm_triton.py:446-471): ys (B,4,C,H,W) -> y (B,C,H*W). */
+int bem_cross_merge_f32(const float* ys, float* y, int B, int C, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused SS2D core (replaces the cross_scan -> x_proj -> dt_proj -> selective_scan chain of
+ * SS2D.forward_corev2, basicsr/vmamba/models/vmamba.py:657-684) for d_state = 1, K = 4.
+ *
+ *   x0  (B,C,L)        activations in row-major pixel order (directions 0 fwd / 2 rev)
+ *   x1  (B,C,L)        the same planes transposed (W,H) (directions 1 fwd / 3 rev)
+ *   xd0 (B,2,R+2,L)    x_proj output rows [dt_0..dt_{R-1}, B, C] of directions {0,2}, row-major order
+ *   xd1 (B,2,R+2,L)    the same for directions {1,3}, transposed order
+ *   dtw (4,C,R), dtb (4,C), A (4C) = -exp(A_logs), Ds (4C)
+ *   y0  (B,C,L)        out: y(dir0) + y(dir2) in row-major order
+ *   y1  (B,C,L)        out: y(dir1) + y(dir3) in transposed order
+ * ------------------------------------------------------------------------------------------- */
+int bem_ss2d_scan_f32(const float* x0, const float* x1, const float* xd0, const float* xd1,
+                      const float* dtw, const float* dtb, const float* A, const float* Ds,
+                      float* y0, float* y1, int B, int C, int L, int R, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Pointwise (1x1) channel-mix GEMM on f32 MFMA with fused prologue / epilogue.  Replaces
+ * Linear2d / nn.Conv2d(k=1) / LayerNorm2d+Linear2d chains (vmamba.py:42-63,123-133,702,715,1326-1334).
+ *
+ *   out[b][m][p] = act( sum_k W[b?][m][k] * pro(x)[b][k][p] + bias[b?][m] ) + res[b][m][p]
+ *   pro: in_mode 0: x = x1 (K = C1) | 1: x = x1 + x2 (K = C1 = C2) | 2: x = cat(x1, x2) (K = C1 + C2);
+ *        then LayerNorm over the K channels of each pixel when ln_w != NULL (eps = ln_eps).
+ *   Wp : weights pre-packed by bem_pack_pw_weight_f32; w_bstride / bias_bstride = element stride
+ *        between per-batch-element weight sets (0 = shared by the whole batch).
+ *   act: 0 none, 1 PReLU with the single slope *prelu.
+ *   out_mode 0: out (B,M,L).  out_mode 1: ConvTranspose2d(k=2,s=2) scatter -- M = 4*Co, row
+ *        (dy*2+dx)*Co + co goes to out (B,Co,2H,2W)[co][2y+dy][2x+dx], L = H*Win.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* x1; const float* x2; int C1; int C2; int in_mode;
+    const float* ln_w; const float* ln_b; float ln_eps;
+    const float* Wp; int64_t w_bstride;
+    const float* bias; int64_t bias_bstride;
+    const float* res;
+    const float* prelu; int act;
+    float* out; int out_mode; int Win;
+    int B; int M; int K; int L;
+} bem_pw_args;
+int bem_pw_gemm_f32(const bem_pw_args* a, void* stream);
+/* natural (nsets, M, K) row-major -> packed MFMA operand order (nsets, MT, KS, 64), MT = ceil(M/32),
+ * KS = ceil(K/2); returns the packed element count per set through *packed_elems when non-NULL. */
+int bem_pack_pw_weight_f32(const float* W, float* Wp, int nsets, int M, int K, void* stream);
+int64_t bem_pw_packed_elems(int M, int K);
+
+/* ---------------------------------------------------------------------------------------------
+ * Convolutions.
+ * ------------------------------------------------------------------------------------------- */
+/* Depthwise 3x3, padding 1 (vmamba.py:507-515 conv2d, :124 gdMlp.dwconv, QD/model4.py:157-165).
+ *   mode 0: out[c] = dw(x[c]) (+bias)            mode 1: SiLU(...)
+ *   mode 2: gdMlp gate, x has 2*Cout channels: out[c] = GELU(dw(x[c])) * dw(x[c+Cout])
+ *   mode 3: PostSmooth: out[c] = x[c] + ReLU(dw(x[c]) + bias)
+ * w: (Cw,1,3,3), bias (Cw) or NULL, Cw = 2*Cout in mode 2 else Cout; *_bstride as above. */
+int bem_dwconv3x3_f32(const float* x, const float* w, int64_t w_bstride, const float* bias,
+                      int64_t bias_bstride, float* out, int B, int Cout, int H, int W, int mode, void* stream);
+
+/* Dense direct convolution KHxKW, given stride / zero padding (nn.Conv2d semantics), optional bias,
+ * ReLU and up to two residual tensors added after the activation:
+ *   out = relu?(conv(x) + bias) + res1 + res2.      x (B,Cin,H,W) -> out (B,Cout,Ho,Wo)
+ * x may be a channel slice of a wider tensor: x_bstride = elements between batch items. */
+int bem_conv2d_f32(const float* x, int64_t x_bstride, const float* w, const float* bias, const float* res1,
+                   const float* res2, float* out, int B, int Cin, int H, int W, int Cout, int KH, int KW,
+                   int stride, int pad, int relu, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Quaternion / Haar primitives (basicsr/QD/model4.py:7-37,216-232; QD/quaternion.py:3-17).
+ * ------------------------------------------------------------------------------------------- */
+/* RGB (B,3,H,W; x_bstride elements between batch items) -> quaternion stack (8 ch) -> Haar DWT
+ * -> out (B,32,H/2,W/2), channel = band*8 + q, bands LL,HL,LH,HH. */
+int bem_quat_dwt_f32(const float* rgb, int64_t x_bstride, float* out, int B, int H, int W, void* stream);
+int bem_dwt_f32(const float* x, float* out, int B, int C, int H, int W, void* stream);
+int bem_iwt_f32(const float* x, float* out, int B, int C4, int H, int W, void* stream);
+/* IWT of q1w, q2w (B,16,h,w) + Hamilton product, real part dropped -> out (B,3,2h,2w).
+ * (DecompDualBranchDDWavelet_arch.py:361-367) */
+int bem_iwt_hamilton_f32(const float* q1w, const float* q2w, float* out, int B, int h, int w, void* stream);
+/* Hamilton product of q[:, 0:4] and q[:, 4:8] (B,8,H,W), real part dropped -> (B,3,H,W). */
+int bem_hamilton_f32(const float* q, float* out, int B, int H, int W, void* stream);
+
+/* Channel cross-attention of the decomposition net (QD/model4.py:81-139) folded with the 1x1 `fuse`
+ * conv that follows it.  Step 1: accumulate per image S = F1 F2^T (32x32), s1 = F1 1, s2 = F2 1 in f64
+ * (stats: (B, 32*32 + 64) doubles, zeroed by the call).  Step 2: softmax + fold all 1x1 weights into
+ * one per-image (32 x 64) matrix + bias (written pre-packed for bem_pw_gemm_f32 in_mode 2). */
+int bem_attn_stats_f64(const float* f1, const float* f2, double* stats, int B, int L, void* stream);
+int bem_attn_fold_f32(const double* stats, const float* attn_w /* 8 x (32x32 + 32): q1,k2,v2,q2,k1,v1,out1,out2 */,
+                      const float* fuse_w /* (32,64) */, const float* fuse_b /* (32) */,
+                      float* Wp_out /* (B, packed(32,64)) */, float* bias_out /* (B,32) */, int B, int L,
+                      void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Layout / resampling helpers.
+ * ------------------------------------------------------------------------------------------- */
+/* (P planes of H x W) -> (P planes of W x H); src/dst plane p at base + (p / ppb) * bstride + (p % ppb) * H*W. */
+int bem_transpose_planes_f32(const float* src, int64_t src_bstride, float* dst, int64_t dst_bstride,
+                             int nbatch, int ppb, int H, int W, void* stream);
+/* dst[b][dst_c0 + c][l] = src[b][c][l]  (c < C), strides in elements. */
+int bem_copy_channels_f32(const float* src, int64_t src_bstride, float* dst, int64_t dst_bstride,
+                          int B, int C, int L, void* stream);
+/* F.interpolate(scale_factor=s, mode='bilinear', align_corners=False) (eval.py:220, UNet_arch.py:130). */
+int bem_bilinear_up_f32(const float* src, int64_t src_bstride, float* dst, int64_t dst_bstride,
+                        int B, int C, int H, int W, int s, void* stream);
+/* PatchMerging gather (UNet_arch.py:74-78): (B,C,H,W) -> (B,4C,H/2,W/2), blocks [ee, oe, eo, oo]. */
+int bem_space_to_depth_f32(const float* x, float* out, int B, int C, int H, int W, void* stream);
+/* nn.PixelShuffle(2): (B,4C,H,W) -> (B,C,2H,2W). */
+int bem_pixel_shuffle2_f32(const float* x, float* out, int B, int C, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Bayesian sampling + Monte-Carlo loop pieces (basicsr/bayesian/conv.py:106-114, eval.py:199-264).
+ * ------------------------------------------------------------------------------------------- */
+/* out[s][i] = mu[i] + log1p(exp(rho[i])) * eps, eps = eps_in[s][i] when eps_in != NULL else a
+ * Philox4x32-10 N(0,1) draw keyed by (seed, stream_id, s*n + i). */
+int bem_bnn_sample_f32(const float* mu, const float* rho, const float* eps_in, float* out,
+                       int nsets, int64_t n, uint64_t seed, uint64_t stream_id, void* stream);
+/* Stage-I post-processing (eval.py:200-209): c = clamp(pred,0,1); if target_mean: c = clamp(c *
+ * target_mean[b_img][ch] / mean_hw(c), 0, 1); c += noise * noise_level.  pred/out (Bn,3,h,w);
+ * target_mean (n_img,3) with image index = b / samples_per_image; noise may be NULL. */
+int bem_cond_postproc_f32(const float* pred, const float* target_mean, const float* noise, float* out,
+                          int Bn, int h, int w, int samples_per_image, float noise_level, void* stream);
+/* Per-plane mean over the top-left (h,w) window of (P, Hs, Ws) planes -> means (P) (f32 out, f64 accumulate). */
+int bem_plane_mean_f32(const float* x, float* means, int P, int Hs, int Ws, int h, int w, void* stream);
+/* Candidate finalisation (eval.py:222-226,246-252, Enhancement/utils.py:5-9): crop to (h,w), clamp to
+ * [0,1], optional per-channel GT-mean rescale + clip, write final (Bn,3,h,w) and PSNR (Bn) vs target
+ * (n_img,3,h,w).  pred is (Bn,3,Hp,Wp). */
+int bem_candidate_finalize_f32(const float* pred, const float* target, float* final_out, float* psnr,
+                               int Bn, int samples_per_image, int Hp, int Wp, int h, int w, int gt_mean,
+                               void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BEM_HIP_H */

@@ -1,0 +1,333 @@
+"""GPU parity: every HIP kernel (through the C ABI / bem.ops) against the CPU oracle on the same
+seeded inputs, plus the reference-generated golden vectors.  Tolerances are stated per test."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, qd_state_dict
+from oracle import bem_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from bem import ops as _ops
+    return _ops
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def close(a, b, rtol=1e-5, atol=1e-6, what=""):
+    a, b = torch.as_tensor(a).detach().cpu().double(), torch.as_tensor(b).detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert torch.isfinite(a).all(), f"{what}: non-finite values"
+    err = (a - b).abs().max().item()
+    assert torch.allclose(a, b, rtol=rtol, atol=atol), f"{what}: max abs err {err:.3e} (ref max {b.abs().max():.3e})"
+
+
+# ----------------------------------------------------------------------------- selective scan ---
+@pytest.mark.parametrize("tag", list("abcde"))
+def test_selective_scan_golden(ops, tag):
+    """bem_selective_scan_fwd_f32 vs the reference's own output; reference f32 tolerance is
+    rtol 6e-4 / atol 2e-3 (test_selective_scan.py:398-405); we hold 1e-4 / 1e-4."""
+    g = load_golden(f"g1_scan_{tag}")
+    D = dev(g["D"]) if "D" in g else None
+    b = dev(g["delta_bias"]) if "delta_bias" in g else None
+    y = ops.selective_scan_fwd(dev(g["u"]), dev(g["delta"]), dev(g["A"]), dev(g["B"]), dev(g["C"]), D, b, True)
+    close(y, g["y"], 1e-4, 1e-4, f"scan {tag}")
+
+
+@pytest.mark.parametrize("shape", [(1, 8, 1, 1), (2, 12, 63, 1), (1, 4, 2049, 1), (1, 8, 5000, 2), (3, 8, 1024, 1), (1, 4, 257, 1)])
+def test_selective_scan_vs_oracle(ops, shape):
+    Bt, KC, L, N = shape
+    g = torch.Generator().manual_seed(L)
+    u, delta = torch.randn(Bt, KC, L, generator=g), 0.5 * torch.rand(Bt, KC, L, generator=g)
+    A = -0.5 * torch.rand(KC, N, generator=g) - 0.01
+    Bm, Cm = torch.randn(Bt, 4, N, L, generator=g), torch.randn(Bt, 4, N, L, generator=g)
+    D, bias = torch.randn(KC, generator=g), 0.5 * torch.rand(KC, generator=g)
+    ref = O.selective_scan_c(u, delta, A, Bm, Cm, D, bias, True)
+    y = ops.selective_scan_fwd(dev(u), dev(delta), dev(A), dev(Bm), dev(Cm), dev(D), dev(bias), True)
+    close(y, ref, 1e-4, 1e-4, f"scan {shape}")
+    ref2 = O.selective_scan_c(u, delta, A, Bm, Cm, None, None, False)
+    y2 = ops.selective_scan_fwd(dev(u), dev(delta), dev(A), dev(Bm), dev(Cm), None, None, False)
+    close(y2, ref2, 1e-4, 1e-4, f"scan nosoftplus {shape}")
+
+
+def test_selective_scan_linearity_full_size(ops):
+    """Size-independent property at the config-2 level-0 size (L = 16384, 160 rows, batch 2):
+    the scan is linear in u for fixed delta/A/B/C -> scan(u1 + 2 u2) = scan(u1) + 2 scan(u2)."""
+    g = torch.Generator().manual_seed(0)
+    Bt, KC, L = 2, 160, 16384
+    u1, u2 = dev(torch.randn(Bt, KC, L, generator=g)), dev(torch.randn(Bt, KC, L, generator=g))
+    delta, A = dev(0.5 * torch.rand(Bt, KC, L, generator=g)), dev(-0.5 * torch.rand(KC, 1, generator=g))
+    Bm, Cm = dev(torch.randn(Bt, 4, 1, L, generator=g)), dev(torch.randn(Bt, 4, 1, L, generator=g))
+    D = dev(torch.randn(KC, generator=g))
+    f = lambda u: ops.selective_scan_fwd(u, delta, A, Bm, Cm, D, None, True)
+    close(f(u1 + 2 * u2), f(u1) + 2 * f(u2), 1e-3, 1e-3, "linearity")
+    # and one row against the C oracle
+    ref = O.selective_scan_c(u1[:1, :4].cpu(), delta[:1, :4].cpu(), A[:4].cpu(), Bm[:1, :1].cpu(), Cm[:1, :1].cpu(), D[:4].cpu(), None, True)
+    y = ops.selective_scan_fwd(u1[:1, :4].contiguous(), delta[:1, :4].contiguous(), A[:4].contiguous(), Bm[:1, :1].contiguous(),
+                               Cm[:1, :1].contiguous(), D[:4].contiguous(), None, True)
+    close(y, ref, 1e-4, 1e-4, "row vs oracle")
+
+
+def test_cross_scan_merge_golden(ops):
+    g = load_golden("g2_cross")
+    assert torch.equal(ops.cross_scan(dev(g["x"])).cpu(), g["xs"])        # pure data movement: bit exact
+    close(ops.cross_merge(dev(g["ys"])), g["y"], 0, 1e-6, "cross_merge")
+
+
+@pytest.mark.parametrize("hw", [(1, 1), (3, 130), (64, 64)])
+def test_cross_scan_merge_shapes(ops, hw):
+    H, W = hw
+    x = torch.randn(2, 3, H, W)
+    assert torch.equal(ops.cross_scan(dev(x)).cpu(), O.cross_scan_ref(x))
+    ys = torch.randn(2, 4, 3, H, W)
+    close(ops.cross_merge(dev(ys)), O.cross_merge_ref(ys), 0, 1e-6)
+
+
+# ----------------------------------------------------------------------------- fused ss2d scan --
+def _ss2d_case(B, C, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    R = -(-C // 16)
+    sd = {"x_proj_weight": torch.randn(4, R + 2, C, generator=g) * C ** -0.5,
+          "dt_projs_weight": (torch.rand(4, C, R, generator=g) - 0.5) * 2 * R ** -0.5,
+          "dt_projs_bias": torch.randn(4, C, generator=g) - 3.0,
+          "A_logs": torch.randn(4 * C, 1, generator=g) * 0.5, "Ds": torch.randn(4 * C, generator=g),
+          "out_norm.weight": torch.ones(C), "out_norm.bias": torch.zeros(C)}
+    x = F.silu(torch.randn(B, C, H, W, generator=g))
+    return sd, x, R
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 4, 4), (1, 40, 16, 12), (2, 16, 7, 10), (1, 24, 64, 48), (1, 8, 33, 70)])
+def test_ss2d_scan_vs_oracle(ops, shape):
+    """transpose -> x_proj GEMMs -> bem_ss2d_scan -> transpose back, against cross_scan/x_proj/dt_proj/
+    selective_scan/cross_merge of the oracle (pre out_norm).  Tolerance 2e-4 rel / 2e-5 abs."""
+    B, C, H, W = shape
+    sd, x, R = _ss2d_case(B, C, H, W, sum(shape))
+    L = H * W
+    # oracle, stopping before out_norm
+    xs = O.cross_scan_ref(x)
+    x_dbl = torch.einsum("bkcl,kjc->bkjl", xs, sd["x_proj_weight"])
+    dts, Bs, Cs = torch.split(x_dbl, [R, 1, 1], dim=2)
+    dts = torch.einsum("bkrl,kcr->bkcl", dts, sd["dt_projs_weight"])
+    ys = O.selective_scan_c(xs.reshape(B, 4 * C, L), dts.reshape(B, 4 * C, L).contiguous(), -torch.exp(sd["A_logs"]),
+                            Bs.contiguous(), Cs.contiguous(), sd["Ds"], sd["dt_projs_bias"].reshape(-1), True)
+    ref = O.cross_merge_ref(ys.reshape(B, 4, C, H, W)).reshape(B, C, H, W)
+    # HIP
+    xc = dev(x)
+    xw = sd["x_proj_weight"]
+    w02 = ops.pack_pw_weight(dev(torch.cat([xw[0], xw[2]], 0)))
+    w13 = ops.pack_pw_weight(dev(torch.cat([xw[1], xw[3]], 0)))
+    xcT = ops.transpose_planes(xc)
+    xd0 = ops.pw_gemm(xc, w02, 2 * (R + 2))
+    xd1 = ops.pw_gemm(xcT, w13, 2 * (R + 2))
+    close(xd0.view(B, 2, R + 2, L)[:, 0], x_dbl[:, 0], 1e-4, 1e-5, "x_dbl dir0")
+    close(xd1.view(B, 2, R + 2, L)[:, 1], x_dbl[:, 3].flip(-1), 1e-4, 1e-5, "x_dbl dir3")
+    y0, y1 = ops.ss2d_scan(xc.view(B, C, L), xcT.view(B, C, L), xd0.view(B, 2, R + 2, L), xd1.view(B, 2, R + 2, L),
+                           dev(sd["dt_projs_weight"]), dev(sd["dt_projs_bias"]), dev(-torch.exp(sd["A_logs"]).reshape(-1)), dev(sd["Ds"]))
+    y = y0.view(B, C, H, W) + ops.transpose_planes(y1.view(B, C, W, H))
+    close(y, ref, 2e-4, 2e-5, f"ss2d {shape}")
+
+
+# ----------------------------------------------------------------------------- pointwise GEMM ---
+@pytest.mark.parametrize("cfg", [(2, 40, 40, 16, 12), (1, 40, 320, 8, 8), (2, 160, 40, 5, 7), (1, 32, 20, 3, 3),
+                                 (3, 64, 33, 4, 130), (1, 7, 5, 2, 2), (1, 320, 160, 32, 32)])
+def test_pw_gemm_plain_bias_res(ops, cfg):
+    """1x1 conv + bias + residual vs F.conv2d.  f32 MFMA = fmaf chain: tolerance 1e-5 * sqrt(K)."""
+    B, K, M, H, W = cfg
+    g = torch.Generator().manual_seed(K * M)
+    x, w = torch.randn(B, K, H, W, generator=g), torch.randn(M, K, generator=g) * K ** -0.5
+    b, r = torch.randn(M, generator=g), torch.randn(B, M, H, W, generator=g)
+    ref = F.conv2d(x, w[:, :, None, None], b) + r
+    y = ops.pw_gemm(dev(x), ops.pack_pw_weight(dev(w)), M, bias=dev(b), res=dev(r))
+    close(y, ref, 1e-4, 2e-5, f"pw {cfg}")
+
+
+def test_pw_gemm_identity_asymmetric(ops):
+    """W = I with an asymmetric input catches a transposed C/D mapping (guide section 3)."""
+    K = 64
+    x = torch.arange(K * 6 * 5, dtype=torch.float32).reshape(1, K, 6, 5)
+    y = ops.pw_gemm(dev(x), ops.pack_pw_weight(dev(torch.eye(K))), K)
+    assert torch.equal(y.cpu(), x)
+    w = torch.zeros(40, 64); w[3, 17] = 2.0; w[39, 0] = -1.0
+    y = ops.pw_gemm(dev(x), ops.pack_pw_weight(dev(w)), 40).cpu()
+    assert torch.equal(y[0, 3], 2 * x[0, 17]) and torch.equal(y[0, 39], -x[0, 0]) and y[0, 5].abs().max() == 0
+
+
+@pytest.mark.parametrize("cfg", [(2, 40, 40, 16, 12), (1, 80, 640, 8, 8), (2, 160, 80, 4, 4), (1, 16, 24, 3, 5)])
+def test_pw_gemm_layernorm(ops, cfg):
+    B, K, M, H, W = cfg
+    g = torch.Generator().manual_seed(K + M)
+    x = torch.randn(B, K, H, W, generator=g) * 2 + 0.5
+    w, lw, lb = torch.randn(M, K, generator=g) * K ** -0.5, torch.randn(K, generator=g), torch.randn(K, generator=g)
+    ref = F.conv2d(O.layernorm2d_ref(x, lw, lb), w[:, :, None, None])
+    y = ops.pw_gemm(dev(x), ops.pack_pw_weight(dev(w)), M, ln=(dev(lw), dev(lb)))
+    close(y, ref, 1e-4, 3e-5, f"ln pw {cfg}")
+
+
+def test_pw_gemm_sum_cat_prelu_perbatch(ops):
+    g = torch.Generator().manual_seed(5)
+    B, C, M, H, W = 3, 24, 40, 6, 10
+    x1, x2 = torch.randn(B, C, H, W, generator=g), torch.randn(B, C, H, W, generator=g)
+    w, lw, lb = torch.randn(M, C, generator=g) * 0.2, torch.randn(C, generator=g), torch.randn(C, generator=g)
+    ref = F.conv2d(O.layernorm2d_ref(x1 + x2, lw, lb), w[:, :, None, None])
+    close(ops.pw_gemm(dev(x1), ops.pack_pw_weight(dev(w)), M, x2=dev(x2), in_mode=1, ln=(dev(lw), dev(lb))), ref, 1e-4, 3e-5, "sum+ln")
+    w2 = torch.randn(M, 2 * C, generator=g) * 0.2
+    a = torch.tensor([0.25])
+    ref = F.prelu(F.conv2d(torch.cat([x1, x2], 1), w2[:, :, None, None]), a)
+    close(ops.pw_gemm(dev(x1), ops.pack_pw_weight(dev(w2)), M, x2=dev(x2), in_mode=2, prelu=dev(a)), ref, 1e-4, 2e-5, "cat+prelu")
+    wb, bb = torch.randn(B, M, C, generator=g) * 0.2, torch.randn(B, M, generator=g)
+    ref = torch.stack([F.conv2d(x1[i:i + 1], wb[i][:, :, None, None], bb[i])[0] for i in range(B)])
+    close(ops.pw_gemm(dev(x1), ops.pack_pw_weight(dev(wb)), M, bias=dev(bb)), ref, 1e-4, 2e-5, "per-batch weights")
+
+
+@pytest.mark.parametrize("cfg", [(2, 16, 8, 4, 6), (1, 160, 80, 8, 8), (1, 6, 3, 3, 5)])
+def test_conv_transpose_2x2(ops, cfg):
+    B, Ci, Co, H, W = cfg
+    from bem.modules import ConvT2x2
+    torch.manual_seed(Ci)
+    m = ConvT2x2(Ci, Co).cuda()
+    x = torch.randn(B, Ci, H, W)
+    ref = F.conv_transpose2d(x, m.weight.detach().cpu(), m.bias.detach().cpu(), stride=2)
+    close(m(dev(x)), ref, 1e-4, 2e-5, f"convT {cfg}")
+
+
+# ----------------------------------------------------------------------------- convolutions -----
+@pytest.mark.parametrize("cfg", [(2, 8, 9, 13), (1, 40, 16, 12), (1, 3, 1, 1), (2, 4, 33, 64)])
+def test_dwconv_modes(ops, cfg):
+    B, C, H, W = cfg
+    g = torch.Generator().manual_seed(C * H)
+    x, w, b = torch.randn(B, C, H, W, generator=g), torch.randn(C, 1, 3, 3, generator=g), torch.randn(C, generator=g)
+    ref = F.conv2d(x, w, b, padding=1, groups=C)
+    close(ops.dwconv3x3(dev(x), dev(w), dev(b), 0), ref, 1e-5, 1e-5, "dw plain")
+    close(ops.dwconv3x3(dev(x), dev(w), None, 1), F.silu(F.conv2d(x, w, None, padding=1, groups=C)), 1e-5, 1e-5, "dw silu")
+    close(ops.dwconv3x3(dev(x), dev(w), dev(b), 3), x + F.relu(ref), 1e-5, 1e-5, "dw postsmooth")
+    if C % 2 == 0:
+        a, c = ref.chunk(2, 1)
+        close(ops.dwconv3x3(dev(x), dev(w), dev(b), 2), F.gelu(a) * c, 1e-5, 1e-5, "dw gate")
+    wb, bb = torch.randn(B, C, 1, 3, 3, generator=g), torch.randn(B, C, generator=g)
+    refb = torch.stack([F.conv2d(x[i:i + 1], wb[i], bb[i], padding=1, groups=C)[0] for i in range(B)])
+    close(ops.dwconv3x3(dev(x), dev(wb), dev(bb), 0), refb, 1e-5, 1e-5, "dw per-batch")
+
+
+@pytest.mark.parametrize("cfg", [(2, 32, 32, 16, 20, 3, 1), (1, 11, 40, 9, 33, 3, 1), (1, 40, 16, 8, 8, 3, 1), (2, 40, 80, 16, 12, 4, 2),
+                                 (1, 3, 40, 5, 7, 3, 1), (1, 80, 160, 6, 10, 4, 2), (1, 40, 3, 70, 40, 3, 1)])
+def test_conv2d(ops, cfg):
+    B, Ci, Co, H, W, k, s = cfg
+    g = torch.Generator().manual_seed(Ci * Co)
+    x, w, b = torch.randn(B, Ci, H, W, generator=g), torch.randn(Co, Ci, k, k, generator=g) * (Ci * k * k) ** -0.5, torch.randn(Co, generator=g)
+    ref = F.conv2d(x, w, b, stride=s, padding=1)
+    close(ops.conv2d(dev(x), dev(w), dev(b), stride=s, pad=1), ref, 1e-4, 2e-5, f"conv {cfg}")
+    r1 = torch.randn_like(ref)
+    close(ops.conv2d(dev(x), dev(w), dev(b), stride=s, pad=1, relu=True, res1=dev(r1), res2=dev(r1)), F.relu(ref) + 2 * r1, 1e-4, 2e-5, "conv relu+res")
+    if Ci > 4:
+        close(ops.conv2d(dev(x), dev(w[:, 2:5].contiguous()), None, stride=s, pad=1, cin_slice=(2, 3)),
+              F.conv2d(x[:, 2:5], w[:, 2:5], None, stride=s, padding=1), 1e-4, 2e-5, "conv channel slice")
+
+
+# ----------------------------------------------------------------------------- Haar / quaternion -
+def test_haar_quaternion_golden(ops):
+    g = load_golden("g3_haar")
+    close(ops.dwt(dev(g["x"])), g["dwt"], 0, 1e-6, "dwt")
+    close(ops.iwt(dev(g["x"])), g["iwt"], 0, 1e-6, "iwt")
+    close(ops.hamilton(dev(torch.cat([g["p"], g["q"]], 1))), g["ham"][:, 1:], 0, 1e-6, "hamilton")
+
+
+def test_quat_dwt_and_iwt_hamilton(ops):
+    g = torch.Generator().manual_seed(11)
+    x6 = torch.rand(2, 6, 10, 14, generator=g)
+    for c0 in (0, 3):
+        close(ops.quat_dwt(dev(x6), c0), O.dwt_ref(O.quaternion_stack_ref(x6[:, c0:c0 + 3])), 0, 1e-6, "quat_dwt")
+    a, b = torch.randn(2, 16, 5, 7, generator=g), torch.randn(2, 16, 5, 7, generator=g)
+    close(ops.iwt_hamilton(dev(a), dev(b)), O.hamilton_ref(O.iwt_ref(a), O.iwt_ref(b))[:, 1:], 1e-6, 1e-6, "iwt_hamilton")
+    # round trip at the full config-2 size: IWT(DWT(x)) == x
+    x = dev(torch.rand(2, 8, 256, 256, generator=g))
+    close(ops.iwt(ops.dwt(x)), x, 0, 1e-6, "haar round trip")
+
+
+# ----------------------------------------------------------------------------- layout helpers ---
+def test_layout_helpers(ops):
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 3, 37, 70, generator=g)
+    assert torch.equal(ops.transpose_planes(dev(x)).cpu(), x.transpose(2, 3).contiguous())
+    d = torch.zeros(2, 7, 37, 70).cuda()
+    ops.copy_channels(dev(x), d, 2, src_c0=1, C=2)
+    assert torch.equal(d[:, 2:4].cpu(), x[:, 1:3]) and d[:, :2].abs().max() == 0 and d[:, 4:].abs().max() == 0
+    y = torch.randn(2, 4, 6, 8, generator=g)
+    s2d = torch.cat([y[:, :, 0::2, 0::2], y[:, :, 1::2, 0::2], y[:, :, 0::2, 1::2], y[:, :, 1::2, 1::2]], 1)
+    assert torch.equal(ops.space_to_depth(dev(y)).cpu(), s2d)
+    z = torch.randn(2, 8, 5, 3, generator=g)
+    assert torch.equal(ops.pixel_shuffle2(dev(z)).cpu(), F.pixel_shuffle(z, 2))
+    for s in (2, 16):
+        c = torch.rand(2, 3, 4, 5, generator=g)
+        close(ops.bilinear_up(dev(c), s), F.interpolate(c, scale_factor=s, mode="bilinear", align_corners=False), 1e-5, 1e-6, f"bilinear x{s}")
+    dst = torch.zeros(2, 6, 64, 80).cuda()
+    c = torch.rand(2, 3, 4, 5, generator=g)
+    ops.bilinear_up(dev(c), 16, dst, 3)
+    close(dst[:, 3:], F.interpolate(c, scale_factor=16, mode="bilinear", align_corners=False), 1e-5, 1e-6, "bilinear into slice")
+    assert dst[:, :3].abs().max() == 0
+
+
+# ----------------------------------------------------------------------------- Bayesian / MC ----
+def test_bnn_sample(ops):
+    g = torch.Generator().manual_seed(13)
+    mu, rho, eps = torch.randn(40, 40, generator=g), torch.randn(40, 40, generator=g) - 3, torch.randn(5, 40, 40, generator=g)
+    ref = mu + torch.log1p(torch.exp(rho)) * eps
+    close(ops.bnn_sample(dev(mu), dev(rho), 5, dev(eps)), ref, 1e-6, 1e-6, "bnn injected eps")
+    # Philox path: recover eps, check N(0,1) moments and independence across sets / stream ids
+    n = 1 << 16
+    z = torch.zeros(n).cuda()
+    rho1 = torch.full((n,), float(np.log(np.expm1(1.0)))).cuda()        # softplus(rho) == 1
+    e = ops.bnn_sample(z, rho1, 4, None, seed=1234, stream_id=7).cpu()
+    assert abs(e.mean()) < 0.01 and abs(e.std() - 1) < 0.01 and abs((e ** 4).mean() - 3) < 0.1
+    assert abs(torch.corrcoef(e[:2])[0, 1]) < 0.02
+    e2 = ops.bnn_sample(z, rho1, 4, None, seed=1234, stream_id=8).cpu()
+    assert not torch.equal(e, e2)
+    assert torch.equal(e, ops.bnn_sample(z, rho1, 4, None, seed=1234, stream_id=7).cpu())   # reproducible
+
+
+def test_mc_postproc_and_finalize(ops):
+    g = torch.Generator().manual_seed(14)
+    N, h, w = 3, 4, 5
+    pred = torch.randn(2 * N, 3, h, w, generator=g) * 0.5 + 0.4
+    tmean = torch.rand(2, 3, generator=g)
+    noise = torch.randn(2 * N, 3, h, w, generator=g)
+    c = pred.clamp(0, 1)
+    ratio = tmean.repeat_interleave(N, 0)[:, :, None, None] / c.mean(dim=(2, 3), keepdim=True)
+    ref = (c * ratio).clamp(0, 1) + noise * 0.1
+    close(ops.cond_postproc(dev(pred), dev(tmean), dev(noise), N, 0.1), ref, 1e-5, 1e-6, "cond postproc")
+    close(ops.cond_postproc(dev(pred), None, None, N, 0.1), c, 0, 0, "cond postproc clamp only")
+    Hp, Wp, hh, ww = 16, 24, 13, 21
+    P = torch.randn(2 * N, 3, Hp, Wp, generator=g) * 0.4 + 0.5
+    T = torch.rand(2, 3, hh, ww, generator=g)
+    close(ops.plane_mean(dev(P), hh, ww), P[:, :, :hh, :ww].mean(dim=(2, 3)), 1e-5, 1e-6, "plane mean")
+    fin, ps = ops.candidate_finalize(dev(P), dev(T), N, hh, ww, True)
+    for i in range(2 * N):
+        q = P[i, :, :hh, :ww].clamp(0, 1).permute(1, 2, 0).numpy()
+        t = T[i // N].permute(1, 2, 0).numpy()
+        q = np.clip(q * (t.mean(axis=(0, 1), keepdims=True) / q.mean(axis=(0, 1), keepdims=True)), 0, 1)
+        close(fin[i].permute(1, 2, 0), q, 1e-5, 1e-6, "final")
+        assert abs(ps[i].item() - O.psnr_ref(t, q)) < 1e-3
+    fin2, _ = ops.candidate_finalize(dev(P), None, N, hh, ww, False)
+    close(fin2, P[:, :, :hh, :ww].clamp(0, 1), 0, 0, "finalize no target")
+
+
+# ----------------------------------------------------------------------------- error behaviour --
+def test_rejects_bad_arguments(ops):
+    from bem.native import BemNativeError
+    x = torch.randn(1, 4, 4, 4)
+    with pytest.raises(BemNativeError):
+        ops.dwt(x)                       # CPU tensor: no CPU path
+    with pytest.raises(ValueError):
+        ops.dwt(dev(torch.randn(1, 4, 5, 4)))
+    with pytest.raises(ValueError):
+        ops.pw_gemm(dev(x), ops.pack_pw_weight(dev(torch.randn(8, 5))), 8)
+    with pytest.raises(BemNativeError):
+        ops.conv2d(dev(x), dev(torch.randn(4, 4, 5, 5)), None, stride=1, pad=2)
