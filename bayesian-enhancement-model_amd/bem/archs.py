@@ -439,7 +439,11 @@ class Network(nn.Module):
         _need_cuda(x)
         if self.training and mask is not None:
             raise BemNativeError("Network: the masked-image-modelling training path is not part of this round")
-        with torch.no_grad():
+        from .modules import _SAMPLE_CTX, SampleCtx, sampling
+        ctx = _SAMPLE_CTX[0]
+        if ctx is None:      # one weight sample per batch element, fresh Philox streams for this forward
+            ctx = SampleCtx(x.shape[0], None, seed=torch.initial_seed() & 0xFFFFFFFF)
+        with torch.no_grad(), sampling(ctx):
             set_module_paths(self)
             x = x.contiguous()
             fea0 = self.first_conv(x)

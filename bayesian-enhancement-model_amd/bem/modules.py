@@ -52,13 +52,18 @@ class SampleCtx:
            (parity runs); when None the draws come from the in-kernel Philox stream (seed, counter).
     """
 
+    _epoch = 0      # process-wide forward counter: successive forwards never reuse a Philox stream
+
     def __init__(self, nsets: int, eps: Optional[Dict[str, torch.Tensor]] = None, seed: int = 0):
         self.nsets, self.eps, self.seed = nsets, eps, seed
         self.counter = 0
+        SampleCtx._epoch += 1
+        self.epoch = SampleCtx._epoch
 
     def next_stream(self):
+        """A fresh Philox stream id per sampled tensor: (forward epoch, tensor counter)."""
         self.counter += 1
-        return self.counter
+        return (self.epoch << 20) + self.counter
 
 
 _SAMPLE_CTX: List[Optional[SampleCtx]] = [None]
@@ -192,7 +197,7 @@ class _BayesBase(nn.Module):
             return self.mu_weight.detach()[None], (self.mu_bias.detach()[None] if self.bias else None), 1
         if self.training:
             raise BemNativeError("Bayesian layers: training-mode forward (EMA prior + KL) is not part of this round")
-        if ctx is None:
+        if ctx is None:      # leaf used outside a Network forward: one-off context (fresh epoch)
             ctx = SampleCtx(B, None, seed=torch.initial_seed() & 0xFFFFFFFF)
         ns = ctx.nsets
         ew = eb = None

@@ -403,3 +403,110 @@ def candidate_finalize(pred, target, samples_per_image, h, w, gt_mean):
     check(lib().bem_candidate_finalize_f32(_p(pred), _p(target), _p(fin), _p(ps), Bn, samples_per_image, Hp, Wp, h, w,
                                            int(bool(gt_mean)), _stream()), "candidate_finalize")
     return fin, ps
+
+
+# --------------------------------------------------------------------------- launch timing ----
+# bench.py asks for ONE op's launches to be bracketed by HIP events on the launch stream (torch's
+# current stream is the stream every wrapper launches on), together with that launch's algorithmic
+# bytes / flops.  Disabled (zero overhead beyond a None check) outside bench.py.
+_PROF = None
+_BOUND = {"pw_gemm": "mfma", "conv2d": "mfma", "dwconv3x3": "hbm", "ss2d_scan": "hbm", "transpose_planes": "hbm"}
+
+
+def profile_start(kernel: str):
+    global _PROF
+    if kernel not in _BOUND:
+        raise ValueError(f"profile_start: unknown op {kernel}; choose from {sorted(_BOUND)}")
+    _PROF = {"kernel": kernel, "events": [], "bytes": 0.0, "flops": 0.0}
+
+
+def profile_stop():
+    global _PROF
+    p, _PROF = _PROF, None
+    if p is None:
+        return None
+    torch.cuda.synchronize()
+    ms = sum(s.elapsed_time(e) for s, e in p["events"])
+    return {"kernel": p["kernel"], "bound": _BOUND[p["kernel"]], "launches": len(p["events"]), "ms": ms,
+            "bytes": p["bytes"], "flops": p["flops"]}
+
+
+def _timed(name, nbytes, nflops):
+    """Decorator-free helper: returns (start_event or None); caller records the end with _timed_end."""
+    if _PROF is None or _PROF["kernel"] != name:
+        return None
+    s = torch.cuda.Event(enable_timing=True)
+    s.record()
+    _PROF["bytes"] += nbytes
+    _PROF["flops"] += nflops
+    return s
+
+
+def _timed_end(s):
+    if s is not None:
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        _PROF["events"].append((s, e))
+
+
+def _wrap_profiled():
+    """Wrap the four hot ops with event brackets + algorithmic byte/flop accounting."""
+    global pw_gemm, conv2d, dwconv3x3, ss2d_scan, transpose_planes
+    _pw, _cv, _dw, _ss, _tp = pw_gemm, conv2d, dwconv3x3, ss2d_scan, transpose_planes
+
+    def pw_gemm_p(x1, Wp, M, **kw):
+        if _PROF is None:
+            return _pw(x1, Wp, M, **kw)
+        B, C1 = x1.shape[0], x1.shape[1]
+        L = x1[0, 0].numel()
+        x2, mode = kw.get("x2"), kw.get("in_mode", 0)
+        K = C1 + (x2.shape[1] if mode == 2 else 0)
+        cin = C1 + (x2.shape[1] if x2 is not None else 0)
+        nb = 4.0 * B * L * (cin + M + (M if kw.get("res") is not None else 0)) + 4.0 * Wp.numel()
+        s = _timed("pw_gemm", nb, 2.0 * M * K * L * B)
+        out = _pw(x1, Wp, M, **kw)
+        _timed_end(s)
+        return out
+
+    def conv2d_p(x, w, bias=None, stride=1, pad=1, **kw):
+        if _PROF is None:
+            return _cv(x, w, bias, stride, pad, **kw)
+        B, _, H, W = x.shape
+        Co, Ci, KH, KW = w.shape
+        Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+        nres = (kw.get("res1") is not None) + (kw.get("res2") is not None)
+        s = _timed("conv2d", 4.0 * B * (Ci * H * W + Co * Ho * Wo * (1 + nres)) + 4.0 * w.numel(), 2.0 * B * Co * Ci * KH * KW * Ho * Wo)
+        out = _cv(x, w, bias, stride, pad, **kw)
+        _timed_end(s)
+        return out
+
+    def dwconv3x3_p(x, w, bias=None, mode=0):
+        if _PROF is None:
+            return _dw(x, w, bias, mode)
+        B, Cin, H, W = x.shape
+        Cout = Cin // 2 if mode == 2 else Cin
+        s = _timed("dwconv3x3", 4.0 * B * H * W * (Cin + Cout), 18.0 * B * Cin * H * W)
+        out = _dw(x, w, bias, mode)
+        _timed_end(s)
+        return out
+
+    def ss2d_scan_p(x0, x1, xd0, xd1, dtw, dtb, A, Ds):
+        if _PROF is None:
+            return _ss(x0, x1, xd0, xd1, dtw, dtb, A, Ds)
+        s = _timed("ss2d_scan", 4.0 * (2 * x0.numel() + 2 * xd0.numel() + 2 * x0.numel()), 0.0)
+        out = _ss(x0, x1, xd0, xd1, dtw, dtb, A, Ds)
+        _timed_end(s)
+        return out
+
+    def transpose_planes_p(x):
+        if _PROF is None:
+            return _tp(x)
+        s = _timed("transpose_planes", 8.0 * x.numel(), 0.0)
+        out = _tp(x)
+        _timed_end(s)
+        return out
+
+    pw_gemm, conv2d, dwconv3x3, ss2d_scan, transpose_planes = pw_gemm_p, conv2d_p, dwconv3x3_p, ss2d_scan_p, transpose_planes_p
+
+
+_wrap_profiled()

@@ -1,0 +1,133 @@
+"""CPU: the C-ABI library loads and exports every symbol include/bem_hip.h declares; the basicsr-compatible
+host layer (registries, option parsing, state-dict key contract, BNN conversion, error behaviour)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, PKG, ROOT
+
+
+@pytest.fixture(scope="module")
+def native():
+    from bem import native as n
+    if not os.path.exists(n.LIB_PATH):
+        n.build()
+    return n
+
+
+def test_header_symbols_exported(native):
+    hdr = open(os.path.join(ROOT, "include", "bem_hip.h")).read()
+    declared = set(re.findall(r"\b(bem_[a-z0-9_]+)\s*\(", hdr))
+    declared.discard("bem_pw_args")
+    assert len(declared) >= 25
+    lib = native.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in bem_hip.h but not exported by libbem_hip.so"
+    assert declared == set(native.SIGNATURES), declared ^ set(native.SIGNATURES)
+    assert lib.bem_abi_version() == 1
+    assert lib.bem_pw_packed_elems(40, 40) == 2 * 20 * 64
+
+
+def test_rejects_null_without_gpu(native):
+    """Argument validation happens before any HIP call, so it is checkable on a GPU-less host."""
+    lib = native.lib()
+    rc = lib.bem_dwt_f32(None, None, 1, 1, 2, 2, None)
+    assert rc == 1 and b"null" in lib.bem_last_error()
+    rc = lib.bem_selective_scan_fwd_f32(*([None] * 8), 1, 4, 8, 1, 1, 1, None)
+    assert rc == 1
+
+
+def test_no_cpu_fallback():
+    from bem import ops
+    from bem.native import BemNativeError
+    import bem.archs as A
+    with pytest.raises(BemNativeError):
+        ops.dwt(torch.zeros(1, 1, 2, 2))
+    net = A.DecompSingleBranch(n_feat=8, num_blocks=[1, 1, 1], decomp_model="model1")
+    with pytest.raises(BemNativeError):
+        net(torch.zeros(1, 6, 16, 16))
+
+
+def test_registry_semantics():
+    from basicsr.utils.registry import ARCH_REGISTRY, MODEL_REGISTRY, Registry
+    import basicsr.archs, basicsr.models  # noqa: F401
+    for n in ("Network", "DecompDualBranchDDWavelet", "DecompSingleBranch"):
+        assert n in ARCH_REGISTRY
+    for n in ("ConditionGenerator", "ImageEnhancer"):
+        assert n in MODEL_REGISTRY
+    with pytest.raises(KeyError):
+        ARCH_REGISTRY.get("NoSuchArch")
+    r = Registry("t")
+
+    @r.register(suffix="basicsr")
+    class Foo:
+        pass
+    assert r.get("Foo") is Foo                     # falls back to Foo_basicsr like the reference
+    with pytest.raises(AssertionError):
+        r.register(Foo, suffix="basicsr")
+
+
+@pytest.mark.parametrize("yml,arch,mtype", [("CG_UNet_LOLv1.yml", "Network", "ConditionGenerator"),
+                                            ("DecompDualBranch2DDWavelet_4.yml", "DecompDualBranchDDWavelet", "ImageEnhancer"),
+                                            ("DecompSingleBranch_1.yml", "DecompSingleBranch", "ImageEnhancer")])
+def test_parse_and_build_model_key_contract(yml, arch, mtype):
+    """parse(yml) -> build_model(opt).net_g has exactly the reference's state-dict keys and shapes
+    (g7_key_contract.npz was written from the reference's own constructors)."""
+    from basicsr.models import build_model
+    from basicsr.utils.options import parse
+    opt = parse(os.path.join(PKG, "Options", yml), is_train=False)
+    assert opt["model_type"] == mtype and opt["is_train"] is False and opt["name"] == yml[:-4]
+    assert opt["condition"]["scale_down"] == 16 and opt["condition"]["noise_level"] == 0.1
+    assert opt["datasets"]["val"]["phase"] == "val" and "results_root" in opt["path"]
+    opt["num_gpu"] = 0
+    net = build_model(opt).net_g
+    ref = np.load(os.path.join(GOLDEN, "g7_key_contract.npz"))[arch].tolist()
+    mine = [f"{k}|{','.join(map(str, v.shape))}" for k, v in net.state_dict().items()]
+    assert sorted(mine) == sorted(ref)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/Options"), reason="reference tree not present")
+def test_reference_option_files_parse():
+    """Every shipped option file of the supported archs parses and builds through the mirror."""
+    from basicsr.archs import build_network
+    from basicsr.utils.options import parse
+    for f in ("DecompDualBranch2DDWavelet_4.yml", "DecompDualBranch2DDWavelet_1.yml", "DecompSingleBranch_1.yml", "DecompSingleBranch_4.yml"):
+        opt = parse(os.path.join("/root/reference/Options", f), is_train=False)
+        net = build_network(opt["network_g"])
+        assert type(net).__name__ == opt["network_g"]["type"]
+
+
+def test_bnn_conversion_and_prediction_type():
+    from basicsr.archs import build_network
+    from basicsr.bayesian import convert2bnn_selective, set_prediction_type
+    net = build_network(dict(type="Network", n_feat=8, num_blocks=[1, 1, 1], d_state=[1, 1, 1], use_pixelshuffle=True))
+    n_det = sum(p.numel() for p in net.parameters())
+    convert2bnn_selective(net, {"sigma_init": 0.05, "decay": 0.998, "pretrain": False})
+    bayes = [(n, m) for n, m in net.named_modules() if hasattr(m, "deterministic")]
+    assert len(bayes) == 6 * 5                                  # 6 leaves per VSSBlock, 5 blocks
+    assert {type(m).__name__ for _, m in bayes} == {"Conv2dReparameterization", "Linear2dReparameterization"}
+    assert all(not m.deterministic for _, m in bayes)
+    set_prediction_type(net, True)
+    assert all(m.deterministic for _, m in bayes)
+    assert sum(p.numel() for p in net.parameters()) > n_det
+    rho = bayes[0][1].rho_weight
+    assert torch.allclose(torch.log1p(torch.exp(rho)), torch.full_like(rho, 0.05), atol=1e-6)   # sigma_init
+    # non-Bayesian parts stay plain (first_conv, proj, PatchMerging, DualUpSample, x_proj/dt_proj/A/D)
+    keys = net.state_dict().keys()
+    assert "first_conv.weight" in keys and "subnets.0.encoder_layers.0.1.reduction.weight" in keys
+    assert "subnets.0.bottleneck.blocks.0.op.x_proj_weight" in keys
+
+
+def test_pad_and_downsample_host_logic():
+    from bem.pipeline import pad_to_multiple, resize_down_linear
+    from oracle import bem_oracle as O
+    x = torch.rand(1, 3, 60, 52)
+    p = pad_to_multiple(x, 64)
+    assert p.shape == (1, 3, 64, 64)
+    ref = O.pad_reflect_ref(x[0].permute(1, 2, 0).numpy(), 64)
+    assert np.array_equal(p[0].permute(1, 2, 0).numpy(), ref)
+    assert pad_to_multiple(torch.rand(1, 3, 128, 64), 64).shape == (1, 3, 128, 64)      # already a multiple: untouched
+    assert torch.allclose(resize_down_linear(p, 16), O.cv2_resize_down(p, 16), atol=1e-7)

@@ -62,7 +62,7 @@ def test_stage2_golden(tag, cls, dm):
     net = getattr(A, cls)(in_channels=6, out_channels=3, n_feat=16, d_state=[1, 1, 1], ssm_ratio=1, mlp_ratio=4, mlp_type="gdmlp",
                           use_pixelshuffle=True, drop_path=0.0, sam=False, stage=1, num_blocks=[2, 1, 1], decomp_model=dm)
     assert list(net.state_dict().keys()) and set(net.state_dict().keys()) == set(g["keys"].tolist())
-    sd = dict(g["sd"]); sd.update(qd_state_dict(dm))
+    sd = dict(g["sd"]); sd.update({k: v for k, v in qd_state_dict(dm).items() if k in net.state_dict()})
     net.load_state_dict(sd, strict=True)
     net.cuda().eval()
     out = net(g["x"].cuda())[-1]
@@ -156,7 +156,7 @@ def test_eval_loop_golden_g8():
     convert2bnn_selective(net1, {"sigma_init": 0.05, "decay": 0.998, "pretrain": False})
     net1.load_state_dict(g["sd1"], strict=True)
     net2 = A.DecompDualBranchDDWavelet(in_channels=6, out_channels=3, decomp_model="model4", **kw)
-    sd2 = dict(g["sd2"]); sd2.update(qd_state_dict("model4"))
+    sd2 = dict(g["sd2"]); sd2.update({k: v for k, v in qd_state_dict("model4").items() if k in net2.state_dict()})
     net2.load_state_dict(sd2, strict=True)
     net1.cuda().eval(); net2.cuda().eval()
     n = g["conds"].shape[0]
