@@ -30,9 +30,14 @@ static inline int bem_check_launch(const char* what) {
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Hardware transcendental forms (v_exp_f32 / v_log_f32, ~1 ulp): the scan evaluates three of them per
+// element and direction, and the libm-accurate versions made that kernel instruction-bound.
+__device__ __forceinline__ float bem_fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float bem_flog(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
 __device__ __forceinline__ float bem_softplus(float x) {
-    // F.softplus, threshold 20 (csms6s.py:54, selective_scan_fwd_kernel_oflex.cuh:125)
-    return x <= 20.f ? log1pf(expf(x)) : x;
+    // F.softplus, threshold 20 (csms6s.py:54, selective_scan_fwd_kernel_oflex.cuh:125).  log(1 + e^x) is
+    // formed directly: for e^x < 2^-24 it returns 0 instead of e^x, an absolute error below 6e-8.
+    return x <= 20.f ? bem_flog(1.f + bem_fexp(x)) : x;
 }
-__device__ __forceinline__ float bem_silu(float x) { return x / (1.f + expf(-x)); }
+__device__ __forceinline__ float bem_silu(float x) { return x / (1.f + bem_fexp(-x)); }
 __device__ __forceinline__ float bem_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }

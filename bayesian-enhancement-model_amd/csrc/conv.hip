@@ -5,71 +5,94 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------------
-// depthwise 3x3, pad 1.  grid (ceil(H*W4/256), Cout, B); each thread produces 4 consecutive pixels.
+// depthwise 3x3, pad 1.  grid (ceil(ceil(H/RB)*W4/256), Cout, B); each thread produces a 4 (x) by RB (y)
+// block of one channel: RB + 2 input rows are read once each as {left scalar, aligned float4, right scalar}.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void dw_rows(const float* __restrict__ plane, int H, int W, int y, int x0,
-                                        const float* __restrict__ w9, float (&acc)[4]) {
+constexpr int RB = 4;
+
+__device__ __forceinline__ void dw_block(const float* __restrict__ plane, int H, int W, int y0, int x0, bool vec,
+                                         const float* __restrict__ w9, float (&acc)[RB][4]) {
+    float wk[9];
 #pragma unroll
-    for (int dy = -1; dy <= 1; ++dy) {
-        const int yy = y + dy;
+    for (int i = 0; i < 9; ++i) wk[i] = w9[i];
+#pragma unroll
+    for (int ry = -1; ry <= RB; ++ry) {
+        const int yy = y0 + ry;
         if (yy < 0 || yy >= H) continue;
         const float* r = plane + (int64_t)yy * W;
         float v[6];
+        v[0] = x0 > 0 ? r[x0 - 1] : 0.f;
+        if (vec) {
+            const float4 c = *reinterpret_cast<const float4*>(r + x0);
+            v[1] = c.x; v[2] = c.y; v[3] = c.z; v[4] = c.w;
+        } else {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int xx = x0 - 1 + i;
-            v[i] = (xx >= 0 && xx < W) ? r[xx] : 0.f;
+            for (int i = 0; i < 4; ++i) v[1 + i] = (x0 + i < W) ? r[x0 + i] : 0.f;
         }
-        const float w0 = w9[(dy + 1) * 3], w1 = w9[(dy + 1) * 3 + 1], w2 = w9[(dy + 1) * 3 + 2];
+        v[5] = (x0 + 4 < W) ? r[x0 + 4] : 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = fmaf(w0, v[j], fmaf(w1, v[j + 1], fmaf(w2, v[j + 2], acc[j])));
+        for (int oy = 0; oy < RB; ++oy) {
+            const int dy = ry - oy;            // compile-time after unrolling
+            if (dy < -1 || dy > 1) continue;
+            const float w0 = wk[(dy + 1) * 3], w1 = wk[(dy + 1) * 3 + 1], w2 = wk[(dy + 1) * 3 + 2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[oy][j] = fmaf(w0, v[j], fmaf(w1, v[j + 1], fmaf(w2, v[j + 2], acc[oy][j])));
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         int64_t w_bs, const float* __restrict__ bias, int64_t b_bs,
                                                         float* __restrict__ out, int Cout, int H, int W, int mode) {
-    const int W4 = (W + 3) >> 2;
+    const int W4 = (W + 3) >> 2, HB = (H + RB - 1) / RB;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= H * W4) return;
-    const int y = i / W4, x0 = (i - y * W4) * 4;
+    if (i >= HB * W4) return;
+    const int yb = i / W4, y0 = yb * RB, x0 = (i - yb * W4) * 4;
     const int c = blockIdx.y, b = blockIdx.z;
     const int Cin = (mode == 2) ? 2 * Cout : Cout;
     const int64_t HW = (int64_t)H * W;
+    const bool vec = (W & 3) == 0;
     const float* wb = w + (int64_t)b * w_bs;
     const float* bb = bias ? bias + (int64_t)b * b_bs : nullptr;
-    float a0[4] = {0.f, 0.f, 0.f, 0.f};
+    float a0[RB][4];
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a0[r][j] = 0.f;
     const float* pl = x + ((int64_t)b * Cin + c) * HW;
-    dw_rows(pl, H, W, y, x0, wb + (int64_t)c * 9, a0);
+    dw_block(pl, H, W, y0, x0, vec, wb + (int64_t)c * 9, a0);
     const float b0 = bb ? bb[c] : 0.f;
-    float o[4];
+    float a1[RB][4];
+    float b1 = 0.f;
     if (mode == 2) {
-        float a1[4] = {0.f, 0.f, 0.f, 0.f};
-        dw_rows(x + ((int64_t)b * Cin + c + Cout) * HW, H, W, y, x0, wb + (int64_t)(c + Cout) * 9, a1);
-        const float b1 = bb ? bb[c + Cout] : 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = bem_gelu(a0[j] + b0) * (a1[j] + b1);
-    } else if (mode == 1) {
+        for (int r = 0; r < RB; ++r)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = bem_silu(a0[j] + b0);
-    } else if (mode == 3) {
+            for (int j = 0; j < 4; ++j) a1[r][j] = 0.f;
+        dw_block(x + ((int64_t)b * Cin + c + Cout) * HW, H, W, y0, x0, vec, wb + (int64_t)(c + Cout) * 9, a1);
+        b1 = bb ? bb[c + Cout] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        const int y = y0 + r;
+        if (y >= H) break;
+        float o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int xx = x0 + j;
-            const float xv = xx < W ? pl[(int64_t)y * W + xx] : 0.f;
-            o[j] = xv + fmaxf(a0[j] + b0, 0.f);
+            const float v = a0[r][j] + b0;
+            if (mode == 2) o[j] = bem_gelu(v) * (a1[r][j] + b1);
+            else if (mode == 1) o[j] = bem_silu(v);
+            else if (mode == 3) o[j] = ((x0 + j < W) ? pl[(int64_t)y * W + x0 + j] : 0.f) + fmaxf(v, 0.f);
+            else o[j] = v;
         }
-    } else {
+        float* op = out + ((int64_t)b * Cout + c) * HW + (int64_t)y * W + x0;
+        if (vec) {
+            *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = a0[j] + b0;
-    }
-    float* op = out + ((int64_t)b * Cout + c) * HW + (int64_t)y * W + x0;
-    if ((W & 3) == 0) {
-        *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (x0 + j < W) op[j] = o[j];
+            for (int j = 0; j < 4; ++j)
+                if (x0 + j < W) op[j] = o[j];
+        }
     }
 }
 
@@ -159,7 +182,7 @@ extern "C" int bem_dwconv3x3_f32(const float* x, const float* w, int64_t w_bstri
     BEM_REQUIRE(B >= 0 && B <= 65535 && Cout > 0 && Cout <= 65535 && H > 0 && W > 0, "dwconv3x3: bad shape");
     BEM_REQUIRE(mode >= 0 && mode <= 3, "dwconv3x3: mode %d", mode);
     if (B == 0) return BEM_OK;
-    dim3 grid(cdiv(H * ((W + 3) / 4), 256), Cout, B);
+    dim3 grid(cdiv(cdiv(H, RB) * ((W + 3) / 4), 256), Cout, B);
     dwconv3x3_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, w, w_bstride, bias, bias_bstride, out, Cout, H, W, mode);
     return bem_check_launch("dwconv3x3");
 }

@@ -15,6 +15,7 @@
 // mean, then centred variance); the two half-waves each see half of the channels, one lane^32 exchange
 // completes them.  The GEMM sweep re-reads x (L1/L2 hits) and normalises on the fly.
 #include "bem_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -178,6 +179,466 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(PwK k) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// v2: LDS-staged variant.  One workgroup = 128 consecutive pixels x ALL output channels:
+//   phase 0  the K x 128 input tile (after the sum / concat prologue) is pulled into LDS with every
+//            load in flight at once (K > KCH is streamed in chunks of KCH channels);
+//   phase 1  LayerNorm in LDS (one thread per pixel for the statistics, all threads normalise);
+//   phase 2  MFMA: B operands come from LDS, A operands (packed weights) from L1/L2 with a register
+//            double buffer 4 k-steps deep.
+//            M-split (MT >= 4): wave w owns M-tiles w, w+4, ..., each against the 4 pixel-interleaved
+//            N-tiles of the workgroup (one ds_read_b128 feeds 4 MFMAs per M-tile);
+//            N-split (MT < 4):  wave w owns the 32 contiguous pixels [32w, 32w+32) against all M-tiles.
+// x is read from HBM exactly once and LayerNorm is evaluated once per pixel, whatever M is.
+// ------------------------------------------------------------------------------------------------
+constexpr int PT = 128;      // pixels per workgroup
+constexpr int KCH = 128;     // channels per LDS chunk when K is streamed
+
+__device__ __forceinline__ void pw2_stage(const PwK& k, float* xs, int b, int p0, int c0, int kc, bool vecL) {
+    // xs[(ch - c0) * PT + pix] for ch in [c0, c0 + kc), pix in [0, PT).  Loads are issued in batches of
+    // UB float4 per thread before anything is written to LDS, so a batch costs one memory latency.
+    constexpr int UB = 8;
+    const int total = kc * (PT / 4);
+    for (int base = 0; base < total; base += 256 * UB) {
+        float4 v[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int idx = base + u * 256 + threadIdx.x;
+            const int cc = idx / (PT / 4), p4 = idx - cc * (PT / 4);
+            const int p = p0 + 4 * p4;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < total && p < k.L) v[u] = load_x(k, b, c0 + cc, p, vecL && (p + 3 < k.L));
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int idx = base + u * 256 + threadIdx.x;
+            if (idx < total) *reinterpret_cast<float4*>(xs + (size_t)idx * 4) = v[u];
+        }
+    }
+}
+
+template <bool MSPLIT>
+__global__ __launch_bounds__(256, 2) void pw_gemm2_kernel(PwK k, int kchunk) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;                           // [kchunk][PT]
+    float* stat = smem + (size_t)kchunk * PT;   // mean[PT], rstd[PT]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, j = lane & 31;
+    const int b = blockIdx.y;
+    const int p0 = blockIdx.x * PT;
+    const bool vecL = (k.L % 4 == 0);
+    const int Kp = 2 * k.KS;                    // K rounded up to even
+    const int nchunks = (Kp + kchunk - 1) / kchunk;
+    const bool ln = k.ln_w != nullptr;          // host guarantees nchunks == 1 with LayerNorm
+
+    constexpr int NI = 2;                        // M-tiles per wave per group (M-split) 
+    constexpr int NACC = MSPLIT ? NI * 4 : 3;
+    const int ngroups = MSPLIT ? (k.MT + 4 * NI - 1) / (4 * NI) : 1;
+    const float slope = (k.act == 1) ? k.prelu[0] : 0.f;
+    const float* bias = k.bias ? k.bias + (int64_t)b * k.bias_bstride : nullptr;
+    const float* wbase = k.Wp + (int64_t)b * k.w_bstride + lane;
+    const int64_t mt_stride = (int64_t)k.KS * 64;
+
+    for (int g = 0; g < ngroups; ++g) {
+        f32x16 acc[NACC];
+#pragma unroll
+        for (int i = 0; i < NACC; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        int mts[MSPLIT ? NI : 3];
+        if (MSPLIT) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) mts[i] = g * 4 * NI + i * 4 + wave;
+        } else {
+            mts[0] = 0; mts[1] = 1; mts[2] = 2;
+        }
+        for (int c = 0; c < nchunks; ++c) {
+            const int c0 = c * kchunk;
+            const int kc = min(kchunk, Kp - c0);
+            if (c > 0 || g == 0 || nchunks > 1) {
+                if (!(g > 0 && nchunks == 1)) {
+                    __syncthreads();            // previous consumers of xs are done
+                    pw2_stage(k, xs, b, p0, c0, kc, vecL);
+                    __syncthreads();
+                    if (ln) {
+                        if (threadIdx.x < PT) {
+                            float s = 0.f;
+                            for (int ch = 0; ch < k.K; ++ch) s += xs[ch * PT + threadIdx.x];
+                            const float mean = s / (float)k.K;
+                            float q = 0.f;
+                            for (int ch = 0; ch < k.K; ++ch) {
+                                const float d = xs[ch * PT + threadIdx.x] - mean;
+                                q = fmaf(d, d, q);
+                            }
+                            stat[threadIdx.x] = mean;
+                            stat[PT + threadIdx.x] = 1.f / sqrtf(q / (float)k.K + k.ln_eps);
+                        }
+                        __syncthreads();
+                        for (int idx = threadIdx.x; idx < k.K * PT; idx += 256) {
+                            const int ch = idx / PT, pp = idx - ch * PT;
+                            xs[idx] = (xs[idx] - stat[pp]) * stat[PT + pp] * k.ln_w[ch] + k.ln_b[ch];
+                        }
+                        __syncthreads();
+                    }
+                }
+            }
+            // ---- MFMA over this chunk ----
+            const int ks0 = c0 >> 1, nks = kc >> 1;
+            if (MSPLIT) {
+                const float* w0 = (mts[0] < k.MT) ? wbase + mts[0] * mt_stride + (int64_t)ks0 * 64 : nullptr;
+                const float* w1 = (mts[1] < k.MT) ? wbase + mts[1] * mt_stride + (int64_t)ks0 * 64 : nullptr;
+                if (w0) {
+                    float a0[4], a1[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        a0[u] = (u < nks) ? w0[u * 64] : 0.f;
+                        a1[u] = (w1 && u < nks) ? w1[u * 64] : 0.f;
+                    }
+                    for (int s0 = 0; s0 < nks; s0 += 4) {
+                        float n0[4], n1[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int sn = s0 + 4 + u;
+                            n0[u] = (sn < nks) ? w0[sn * 64] : 0.f;
+                            n1[u] = (w1 && sn < nks) ? w1[sn * 64] : 0.f;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (s0 + u < nks) {
+                                const float4 xv = *reinterpret_cast<const float4*>(xs + (2 * (s0 + u) + half) * PT + 4 * j);
+                                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], xv.x, acc[0], 0, 0, 0);
+                                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], xv.y, acc[1], 0, 0, 0);
+                                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], xv.z, acc[2], 0, 0, 0);
+                                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], xv.w, acc[3], 0, 0, 0);
+                                if (w1) {
+                                    acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], xv.x, acc[4], 0, 0, 0);
+                                    acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], xv.y, acc[5], 0, 0, 0);
+                                    acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], xv.z, acc[6], 0, 0, 0);
+                                    acc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], xv.w, acc[7], 0, 0, 0);
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { a0[u] = n0[u]; a1[u] = n1[u]; }
+                    }
+                }
+            } else {
+                const float* w0 = wbase + (int64_t)ks0 * 64;
+                float an[3][4];
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) an[m][u] = (m < k.MT && u < nks) ? w0[m * mt_stride + (int64_t)u * 64] : 0.f;
+                for (int s0 = 0; s0 < nks; s0 += 4) {
+                    float ac[3][4];
+#pragma unroll
+                    for (int m = 0; m < 3; ++m)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            ac[m][u] = an[m][u];
+                            const int sn = s0 + 4 + u;
+                            an[m][u] = (m < k.MT && sn < nks) ? w0[m * mt_stride + (int64_t)sn * 64] : 0.f;
+                        }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (s0 + u < nks) {
+                            const float xv = xs[(2 * (s0 + u) + half) * PT + 32 * wave + j];
+#pragma unroll
+                            for (int m = 0; m < 3; ++m)
+                                if (m < k.MT) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[m][u], xv, acc[m], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        // ---- epilogue of this group ----
+        // Residual values are fetched for a whole M-tile BEFORE anything is stored: `res` and `out` may alias as
+        // far as the compiler knows, so interleaving them serialises one memory latency per row.
+        constexpr int NM = MSPLIT ? NI : 3;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const int mt = mts[m];
+            if (mt >= k.MT) continue;
+            const int rbase = mt * 32 + 4 * half;
+            if (MSPLIT) {
+                const int p = p0 + 4 * j;
+                if (p >= k.L) continue;
+                const bool vec = vecL && (p + 3 < k.L);
+#pragma unroll
+                for (int rh = 0; rh < 16; rh += 8) {       // residual rows fetched 8 at a time (register budget)
+                    float4 rv[8];
+                    if (k.res && k.out_mode == 0) {
+#pragma unroll
+                        for (int r8 = 0; r8 < 8; ++r8) {
+                            const int r = rh + r8;
+                            const int row = rbase + (r & 3) + 8 * (r >> 2);
+                            rv[r8] = (row < k.M) ? ld4(k.res + ((int64_t)b * k.M + row) * k.L, p, k.L, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
+                    }
+#pragma unroll
+                    for (int r8 = 0; r8 < 8; ++r8) {
+                        const int r = rh + r8;
+                        const int row = rbase + (r & 3) + 8 * (r >> 2);
+                        if (row >= k.M) continue;
+                        const float bv = bias ? bias[row] : 0.f;
+                        float o[4] = {acc[m * 4 + 0][r] + bv, acc[m * 4 + 1][r] + bv, acc[m * 4 + 2][r] + bv, acc[m * 4 + 3][r] + bv};
+                        if (k.act == 1) {
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) o[v] = o[v] >= 0.f ? o[v] : slope * o[v];
+                        }
+                        if (k.out_mode == 0) {
+                            const int64_t base = ((int64_t)b * k.M + row) * k.L;
+                            if (k.res) { o[0] += rv[r8].x; o[1] += rv[r8].y; o[2] += rv[r8].z; o[3] += rv[r8].w; }
+                            if (vec) {
+                                *reinterpret_cast<float4*>(k.out + base + p) = make_float4(o[0], o[1], o[2], o[3]);
+                            } else {
+#pragma unroll
+                                for (int v = 0; v < 4; ++v)
+                                    if (p + v < k.L) k.out[base + p + v] = o[v];
+                            }
+                        } else {
+                            const int Co = k.M >> 2;
+                            const int q = row / Co, co = row - q * Co;
+                            const int64_t obase = ((int64_t)b * Co + co) * (4 * (int64_t)k.L);
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) {
+                                const int pp = p + v;
+                                if (pp < k.L) {
+                                    const int yy = pp / k.Win, xx = pp - yy * k.Win;
+                                    k.out[obase + (int64_t)(2 * yy + (q >> 1)) * (2 * k.Win) + (2 * xx + (q & 1))] = o[v];
+                                }
+                            }
+                        }
+                    }
+                }
+            } else {
+                const int p = p0 + 32 * wave + j;
+                if (p >= k.L) continue;
+                float rv[16];
+                if (k.res && k.out_mode == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rbase + (r & 3) + 8 * (r >> 2);
+                        rv[r] = (row < k.M) ? k.res[((int64_t)b * k.M + row) * k.L + p] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    if (row >= k.M) continue;
+                    float o = acc[m][r] + (bias ? bias[row] : 0.f);
+                    if (k.act == 1) o = o >= 0.f ? o : slope * o;
+                    if (k.out_mode == 0) {
+                        if (k.res) o += rv[r];
+                        k.out[((int64_t)b * k.M + row) * k.L + p] = o;
+                    } else {
+                        const int Co = k.M >> 2;
+                        const int q = row / Co, co = row - q * Co;
+                        const int yy = p / k.Win, xx = p - yy * k.Win;
+                        k.out[((int64_t)b * Co + co) * (4 * (int64_t)k.L) + (int64_t)(2 * yy + (q >> 1)) * (2 * k.Win) + (2 * xx + (q & 1))] = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// v3: barrier-free variants (each wave is an independent 128-pixel worker, as in v1).
+//   pw_gemm3_reg<KSM, MTW>  K <= 2*KSM: the wave's whole input tile lives in registers (KSM float4 per lane,
+//       all loads issued back to back = one memory latency), LayerNorm is evaluated on those registers, and the
+//       wave then walks over ALL M-tiles, MTW at a time.  x is read once, LN computed once.
+//   pw_gemm3_stream<MTW>    any K, no LayerNorm: x is streamed in batches of 8 k-steps, the next batch being
+//       requested before the MFMAs of the current one (explicit software pipeline); grid.y walks M slices.
+// ------------------------------------------------------------------------------------------------
+template <int MTW>
+__device__ __forceinline__ void pw3_epilogue(const PwK& k, int b, int mt0, int p, bool vec, int half,
+                                             const f32x16 (&acc)[MTW][4]) {
+    const float slope = (k.act == 1) ? k.prelu[0] : 0.f;
+    const float* bias = k.bias ? k.bias + (int64_t)b * k.bias_bstride : nullptr;
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+        if (mt0 + m >= k.MT) continue;
+        const int rbase = (mt0 + m) * 32 + 4 * half;
+#pragma unroll
+        for (int rh = 0; rh < 16; rh += 4) {
+            float4 rv[4];
+            if (k.res && k.out_mode == 0) {
+#pragma unroll
+                for (int r8 = 0; r8 < 4; ++r8) {
+                    const int r = rh + r8;
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    rv[r8] = (row < k.M) ? ld4(k.res + ((int64_t)b * k.M + row) * k.L, p, k.L, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int r8 = 0; r8 < 4; ++r8) {
+                const int r = rh + r8;
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (row >= k.M) continue;
+                const float bv = bias ? bias[row] : 0.f;
+                float o[4] = {acc[m][0][r] + bv, acc[m][1][r] + bv, acc[m][2][r] + bv, acc[m][3][r] + bv};
+                if (k.act == 1) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) o[v] = o[v] >= 0.f ? o[v] : slope * o[v];
+                }
+                if (k.out_mode == 0) {
+                    const int64_t base = ((int64_t)b * k.M + row) * k.L;
+                    if (k.res) { o[0] += rv[r8].x; o[1] += rv[r8].y; o[2] += rv[r8].z; o[3] += rv[r8].w; }
+                    if (vec) {
+                        *reinterpret_cast<float4*>(k.out + base + p) = make_float4(o[0], o[1], o[2], o[3]);
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+                            if (p + v < k.L) k.out[base + p + v] = o[v];
+                    }
+                } else {
+                    const int Co = k.M >> 2;
+                    const int q = row / Co, co = row - q * Co;
+                    const int64_t obase = ((int64_t)b * Co + co) * (4 * (int64_t)k.L);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int pp = p + v;
+                        if (pp < k.L) {
+                            const int yy = pp / k.Win, xx = pp - yy * k.Win;
+                            k.out[obase + (int64_t)(2 * yy + (q >> 1)) * (2 * k.Win) + (2 * xx + (q & 1))] = o[v];
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int KSM, int MTW>
+__global__ __launch_bounds__(256, (KSM > 20 ? 1 : 2)) void pw_gemm3_reg_kernel(PwK k) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+    const int b = blockIdx.z;
+    const int p = (blockIdx.x * 4 + wave) * 128 + 4 * (lane & 31);
+    if (p - 4 * (lane & 31) >= k.L) return;
+    const bool vec = (k.L % 4 == 0) && (p + 3 < k.L);
+    const bool any = p < k.L;
+    float4 xr[KSM];
+#pragma unroll
+    for (int st = 0; st < KSM; ++st)
+        xr[st] = (any && st < k.KS) ? load_x(k, b, 2 * st + half, p, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k.ln_w) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int st = 0; st < KSM; ++st) { s.x += xr[st].x; s.y += xr[st].y; s.z += xr[st].z; s.w += xr[st].w; }
+        s.x += __shfl_xor(s.x, 32, 64); s.y += __shfl_xor(s.y, 32, 64);
+        s.z += __shfl_xor(s.z, 32, 64); s.w += __shfl_xor(s.w, 32, 64);
+        const float inv = 1.f / (float)k.K;
+        const float4 mean = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int st = 0; st < KSM; ++st) {
+            if (2 * st + half < k.K) {
+                const float dx = xr[st].x - mean.x, dy = xr[st].y - mean.y, dz = xr[st].z - mean.z, dw = xr[st].w - mean.w;
+                q.x = fmaf(dx, dx, q.x); q.y = fmaf(dy, dy, q.y); q.z = fmaf(dz, dz, q.z); q.w = fmaf(dw, dw, q.w);
+            }
+        }
+        q.x += __shfl_xor(q.x, 32, 64); q.y += __shfl_xor(q.y, 32, 64);
+        q.z += __shfl_xor(q.z, 32, 64); q.w += __shfl_xor(q.w, 32, 64);
+        const float4 rstd = make_float4(1.f / sqrtf(q.x * inv + k.ln_eps), 1.f / sqrtf(q.y * inv + k.ln_eps),
+                                        1.f / sqrtf(q.z * inv + k.ln_eps), 1.f / sqrtf(q.w * inv + k.ln_eps));
+#pragma unroll
+        for (int st = 0; st < KSM; ++st) {
+            const int ch = 2 * st + half;
+            if (ch < k.K) {
+                const float g = k.ln_w[ch], be = k.ln_b[ch];
+                xr[st].x = (xr[st].x - mean.x) * rstd.x * g + be;
+                xr[st].y = (xr[st].y - mean.y) * rstd.y * g + be;
+                xr[st].z = (xr[st].z - mean.z) * rstd.z * g + be;
+                xr[st].w = (xr[st].w - mean.w) * rstd.w * g + be;
+            }
+        }
+    }
+    const float* wbase = k.Wp + (int64_t)b * k.w_bstride + lane;
+    const int64_t mt_stride = (int64_t)k.KS * 64;
+    for (int mt0 = 0; mt0 < k.MT; mt0 += MTW) {
+        f32x16 acc[MTW][4];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][v][r] = 0.f;
+        const float* wp = wbase + (int64_t)mt0 * mt_stride;
+#pragma unroll
+        for (int st = 0; st < KSM; ++st) {
+            if (st < k.KS) {
+                float av[MTW];
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) av[m] = (mt0 + m < k.MT) ? wp[m * mt_stride + (int64_t)st * 64] : 0.f;
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) {
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], xr[st].x, acc[m][0], 0, 0, 0);
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], xr[st].y, acc[m][1], 0, 0, 0);
+                    acc[m][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], xr[st].z, acc[m][2], 0, 0, 0);
+                    acc[m][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], xr[st].w, acc[m][3], 0, 0, 0);
+                }
+            }
+        }
+        if (any) pw3_epilogue<MTW>(k, b, mt0, p, vec, half, acc);
+    }
+}
+
+template <int MTW>
+__global__ __launch_bounds__(256, 2) void pw_gemm3_stream_kernel(PwK k) {
+    constexpr int PF = 4;   // k-steps per batch; two register batches alternate (load one, multiply the other)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+    const int b = blockIdx.z;
+    const int mt0 = blockIdx.y * MTW;
+    const int p = (blockIdx.x * 4 + wave) * 128 + 4 * (lane & 31);
+    if (p - 4 * (lane & 31) >= k.L) return;
+    const bool vec = (k.L % 4 == 0) && (p + 3 < k.L);
+    const bool any = p < k.L;
+    f32x16 acc[MTW][4];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][v][r] = 0.f;
+    const float* wp = k.Wp + (int64_t)b * k.w_bstride + ((int64_t)mt0 * k.KS) * 64 + lane;
+    const int64_t mt_stride = (int64_t)k.KS * 64;
+    auto load_batch = [&](int s0, float4 (&xb)[PF], float (&ab)[MTW][PF]) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int sn = s0 + u;
+            xb[u] = (any && sn < k.KS) ? load_x(k, b, 2 * sn + half, p, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) ab[m][u] = (mt0 + m < k.MT && sn < k.KS) ? wp[m * mt_stride + (int64_t)sn * 64] : 0.f;
+        }
+    };
+    auto mma_batch = [&](int s0, const float4 (&xb)[PF], const float (&ab)[MTW][PF]) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            if (s0 + u < k.KS) {
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) {
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[m][u], xb[u].x, acc[m][0], 0, 0, 0);
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[m][u], xb[u].y, acc[m][1], 0, 0, 0);
+                    acc[m][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[m][u], xb[u].z, acc[m][2], 0, 0, 0);
+                    acc[m][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[m][u], xb[u].w, acc[m][3], 0, 0, 0);
+                }
+            }
+        }
+    };
+    float4 xA[PF], xB[PF];
+    float aA[MTW][PF], aB[MTW][PF];
+    load_batch(0, xA, aA);
+    for (int s0 = 0; s0 < k.KS; s0 += 2 * PF) {
+        load_batch(s0 + PF, xB, aB);
+        mma_batch(s0, xA, aA);
+        load_batch(s0 + 2 * PF, xA, aA);
+        mma_batch(s0 + PF, xB, aB);
+    }
+    if (any) pw3_epilogue<MTW>(k, b, mt0, p, vec, half, acc);
+}
+
 __global__ void pack_pw_weight_kernel(const float* __restrict__ W, float* __restrict__ Wp, int M, int K, int MT, int KS) {
     // grid: (ceil(MT*KS*64 / 256), nsets)
     const int64_t per = (int64_t)MT * KS * 64;
@@ -225,6 +686,44 @@ extern "C" int bem_pw_gemm_f32(const bem_pw_args* a, void* stream) {
     k.res = a->res; k.prelu = a->prelu; k.act = a->act; k.out = a->out; k.out_mode = a->out_mode; k.Win = a->Win;
     k.M = a->M; k.K = a->K; k.L = a->L; k.KS = cdiv(a->K, 2); k.MT = cdiv(a->M, 32);
     hipStream_t s = (hipStream_t)stream;
+    const int Kp = 2 * k.KS;
+    const bool ln = a->ln_w != nullptr;
+    static int force_v1 = getenv("BEM_PW_V1") ? atoi(getenv("BEM_PW_V1")) : 0;   // 1: v1 only, 2: v2/v1 only
+    if (!force_v1) {
+        // v3: barrier-free.  Register-resident input for K <= 80 (LayerNorm or not), software-pipelined stream otherwise.
+        dim3 grid(cdiv(a->L, 512), 1, a->B);
+        if (k.KS <= 20) {
+            if (k.MT == 1) pw_gemm3_reg_kernel<20, 1><<<grid, 256, 0, s>>>(k);
+            else pw_gemm3_reg_kernel<20, 2><<<grid, 256, 0, s>>>(k);
+            return bem_check_launch("pw_gemm3_reg");
+        }
+        if (!ln) {
+            if (k.MT == 1) {
+                pw_gemm3_stream_kernel<1><<<grid, 256, 0, s>>>(k);
+            } else {
+                grid.y = cdiv(k.MT, 2);
+                pw_gemm3_stream_kernel<2><<<grid, 256, 0, s>>>(k);
+            }
+            return bem_check_launch("pw_gemm3_stream");
+        }
+    }
+    if (force_v1 != 1 && !(ln && Kp > 160)) {
+        // v2: LDS-staged.  LayerNorm needs the whole K in LDS (<= 160 channels = 80 KiB); otherwise stream KCH-channel chunks.
+        const int kchunk = ln ? Kp : (Kp < KCH ? Kp : KCH);
+        const size_t lds = ((size_t)kchunk * PT + 2 * PT) * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            attr_set = true;
+        }
+        dim3 grid(cdiv(a->L, PT), a->B);
+        if (k.MT >= 4)
+            pw_gemm2_kernel<true><<<grid, 256, lds, s>>>(k, kchunk);
+        else
+            pw_gemm2_kernel<false><<<grid, 256, lds, s>>>(k, kchunk);
+        return bem_check_launch("pw_gemm2");
+    }
     if (k.MT == 1) {
         dim3 grid(cdiv(a->L, 512), 1, a->B);
         pw_gemm_kernel<1><<<grid, 256, 0, s>>>(k);

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(NT) void selective_scan_fwd_kernel(
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const bool ok = t0 + e < L;
-                a[e] = ok ? expf(dt[e] * An) : 1.f;
+                a[e] = ok ? bem_fexp(dt[e] * An) : 1.f;
                 bb[e] = ok ? dt[e] * Bv[e] * uu[e] : 0.f;
             }
             float carry = carry_s[n];
@@ -188,7 +188,7 @@ __device__ __forceinline__ void ss2d_coeffs(const float* __restrict__ xd /* (R+2
     for (int e = 0; e < E; ++e) {
         const bool ok = t0 + e < L;
         const float dl = bem_softplus(dt[e] + dtb);
-        a[e] = ok ? expf(dl * Ak) : 1.f;
+        a[e] = ok ? bem_fexp(dl * Ak) : 1.f;
         b[e] = ok ? dl * Bv[e] * x[e] : 0.f;
     }
 }
