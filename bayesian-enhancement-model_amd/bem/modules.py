@@ -9,6 +9,7 @@ the modules run under ``torch.no_grad`` semantics (outputs carry no autograd gra
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -36,6 +37,9 @@ class _Cache:
             val = fn()
         self._d[key] = (sig, val)
         return val
+
+
+FUSE_GDMLP = os.environ.get("BEM_FUSE_GDMLP", "0") != "0"    # 0: unfused three-kernel gdMlp (kept for A/B checks)
 
 
 def _need_cuda(x):
@@ -272,6 +276,10 @@ class Linear2dReparameterization(_BayesBase):
 # ------------------------------------------------------------------------------------------------
 # SS2D / gdMlp / VSSBlock  (basicsr/vmamba/models/vmamba.py:116-133, 438-716, 1241-1334)
 # ------------------------------------------------------------------------------------------------
+def _has_bias(m):
+    return (m.bias is not None) if isinstance(m, nn.Conv2d) else bool(m.bias)
+
+
 def _out_features(m):
     return m.out_features if hasattr(m, "out_features") else m.out_channels
 
@@ -285,10 +293,34 @@ class gdMlp(nn.Module):
         self.dwconv = DwConv2d(hidden_features * 2)
         self.project_out = PwConv2d(hidden_features, out_features)
         self.act = act_layer()
+        self._cache = _Cache()
+
+    def _fused_params(self, B):
+        """(Wpi gate-packed, bpi, dww, dwb, Wpo packed, bpo) -- cached when deterministic, drawn per call when Bayesian."""
+        pi, dw, po = self.project_in, self.dwconv, self.project_out
+        Hd = pi.out_channels // 2
+        if isinstance(pi, PwConv2d):
+            def prep():
+                return (ops.pack_pw_weight_gate(pi.weight.detach().reshape(2 * Hd, -1).contiguous(), Hd), pi.bias.detach().contiguous(),
+                        dw.weight.detach().reshape(2 * Hd, 9).contiguous(), None if dw.bias is None else dw.bias.detach().contiguous(),
+                        ops.pack_pw_weight(po.weight.detach().reshape(po.out_channels, Hd).contiguous()),
+                        None if po.bias is None else po.bias.detach().contiguous())
+            return self._cache.get("fused", [pi.weight, pi.bias, dw.weight, po.weight], prep)
+        w, b, ns = pi._sampled(B)
+        Wpi = ops.pack_pw_weight_gate(w.reshape(ns, 2 * Hd, -1).contiguous(), Hd)
+        w2, b2, _ = dw._sampled(B)
+        w3, b3, _ = po._sampled(B)
+        Wpo = ops.pack_pw_weight(w3.reshape(ns, po.out_channels, Hd).contiguous())
+        return Wpi, b.contiguous(), w2.reshape(ns, 2 * Hd * 9).contiguous(), (None if b2 is None else b2.contiguous()), Wpo, \
+            (None if b3 is None else b3.contiguous())
 
     def forward_fused(self, x, norm: LayerNorm2d):
         """x + project_out(GELU(h1) * h2), h = dwconv(project_in(LN(x)))."""
-        B = x.shape[0]
+        B, C = x.shape[0], x.shape[1]
+        Hd = self.project_in.out_channels // 2
+        if FUSE_GDMLP and ops.gdmlp_fused_supported(C, Hd) and _has_bias(self.project_in):
+            Wpi, bpi, dww, dwb, Wpo, bpo = self._fused_params(B)
+            return ops.gdmlp_fused(x, norm.weight.detach(), norm.bias.detach(), norm.eps, Wpi, bpi, dww, dwb, Wpo, bpo, Hd)
         Wp, b = self.project_in.gemm_weights(B)
         t = ops.pw_gemm(x, Wp, _out_features(self.project_in), ln=(norm.weight.detach(), norm.bias.detach()),
                         ln_eps=norm.eps, bias=b)

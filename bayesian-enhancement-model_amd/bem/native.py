@@ -31,6 +31,17 @@ class PwArgs(ctypes.Structure):
     ]
 
 
+class GdmlpArgs(ctypes.Structure):
+    """Mirror of ``bem_gdmlp_args`` (include/bem_hip.h)."""
+    _fields_ = [
+        ("x", c_void_p), ("out", c_void_p), ("ln_w", c_void_p), ("ln_b", c_void_p), ("ln_eps", c_float),
+        ("Wpi", c_void_p), ("wpi_bstride", c_int64), ("bpi", c_void_p), ("bpi_bstride", c_int64),
+        ("dww", c_void_p), ("dww_bstride", c_int64), ("dwb", c_void_p), ("dwb_bstride", c_int64),
+        ("Wpo", c_void_p), ("wpo_bstride", c_int64), ("bpo", c_void_p), ("bpo_bstride", c_int64),
+        ("B", c_int), ("C", c_int), ("Hd", c_int), ("H", c_int), ("W", c_int),
+    ]
+
+
 P, I, I64, U64, F = c_void_p, c_int, c_int64, c_uint64, c_float
 
 # name -> argtypes (return type int unless listed in _RESTYPE); this table is what the
@@ -43,6 +54,8 @@ SIGNATURES = {
     "bem_pw_gemm_f32": [ctypes.POINTER(PwArgs), P],
     "bem_pack_pw_weight_f32": [P, P, I, I, I, P],
     "bem_pw_packed_elems": [I, I],
+    "bem_gdmlp_fused_f32": [ctypes.POINTER(GdmlpArgs), P],
+    "bem_pack_pw_weight_gate_f32": [P, P, I, I, I, P],
     "bem_dwconv3x3_f32": [P, P, I64, P, I64, P, I, I, I, I, I, P],
     "bem_conv2d_f32": [P, I64, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "bem_quat_dwt_f32": [P, I64, P, I, I, I, P],

@@ -171,6 +171,59 @@ def pw_gemm(x1, Wp, M, *, x2=None, in_mode=0, ln=None, ln_eps=1e-5, bias=None, r
     return out
 
 
+def pack_pw_weight_gate(W, Hd):
+    """project_in weight (2Hd,K) or (nsets,2Hd,K) -> packed with gate rows regrouped per 16 channels."""
+    _chk(W, "W")
+    if W.dim() == 2:
+        W = W[None]
+    ns, M, K = W.shape
+    if M != 2 * Hd or Hd % 16:
+        raise ValueError("pack_pw_weight_gate: expects (2*Hd, K) with Hd % 16 == 0")
+    out = torch.empty(ns, (Hd // 16) * ((K + 1) // 2) * 64, device=W.device, dtype=W.dtype)
+    check(lib().bem_pack_pw_weight_gate_f32(_p(W), _p(out), ns, Hd, K, _stream()), "pack_pw_weight_gate")
+    return out
+
+
+def gdmlp_fused_supported(C, Hd):
+    return C <= 160 and Hd % 16 == 0
+
+
+def gdmlp_fused(x, ln_w, ln_b, ln_eps, Wpi, bpi, dww, dwb, Wpo, bpo, Hd):
+    """x (B,C,H,W) -> x + project_out(GELU(dw(h1)) * dw(h2)), h = project_in(LN(x)); see bem_gdmlp_fused_f32."""
+    for n, t in (("x", x), ("ln_w", ln_w), ("ln_b", ln_b), ("Wpi", Wpi), ("bpi", bpi), ("dww", dww), ("Wpo", Wpo)):
+        _chk(t, n)
+    _chk(dwb, "dwb", optional=True); _chk(bpo, "bpo", optional=True)
+    B, C, H, W = x.shape
+    KS = (C + 1) // 2
+
+    def bs(t, per):     # (tensor with optional leading batch dim) -> element stride between sets
+        if t is None:
+            return 0
+        n = t.numel()
+        if n == per:
+            return 0
+        if n == B * per:
+            return per
+        raise ValueError(f"gdmlp_fused: parameter of {n} elements matches neither {per} nor {B}x{per}")
+    a = native.GdmlpArgs()
+    a.x, a.ln_w, a.ln_b, a.ln_eps = x.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), ln_eps
+    if ln_w.numel() != C or ln_b.numel() != C:
+        raise ValueError("gdmlp_fused: LayerNorm size")
+    a.Wpi, a.wpi_bstride = Wpi.data_ptr(), bs(Wpi, (Hd // 16) * KS * 64)
+    a.bpi, a.bpi_bstride = bpi.data_ptr(), bs(bpi, 2 * Hd)
+    a.dww, a.dww_bstride = dww.data_ptr(), bs(dww, 2 * Hd * 9)
+    a.dwb, a.dwb_bstride = (dwb.data_ptr() if dwb is not None else 0), bs(dwb, 2 * Hd)
+    a.Wpo, a.wpo_bstride = Wpo.data_ptr(), bs(Wpo, packed_elems(C, Hd))
+    a.bpo, a.bpo_bstride = (bpo.data_ptr() if bpo is not None else 0), bs(bpo, C)
+    out = torch.empty_like(x)
+    a.out = out.data_ptr()
+    a.B, a.C, a.Hd, a.H, a.W = B, C, Hd, H, W
+    s = _timed("gdmlp_fused", 8.0 * x.numel(), 2.0 * B * H * W * (2 * Hd * C + Hd * C + 2 * Hd * 9)) if _PROF is not None else None
+    check(lib().bem_gdmlp_fused_f32(ctypes.byref(a), _stream()), "gdmlp_fused")
+    _timed_end(s)
+    return out
+
+
 # --------------------------------------------------------------------------- convolutions -----
 def dwconv3x3(x, w, bias=None, mode=0):
     """mode 0 plain, 1 SiLU, 2 gdMlp gate (x has 2*Cout channels), 3 PostSmooth.  w (Cw,1,3,3) or (B,Cw,1,3,3)."""
@@ -410,7 +463,7 @@ def candidate_finalize(pred, target, samples_per_image, h, w, gt_mean):
 # current stream is the stream every wrapper launches on), together with that launch's algorithmic
 # bytes / flops.  Disabled (zero overhead beyond a None check) outside bench.py.
 _PROF = None
-_BOUND = {"pw_gemm": "mfma", "conv2d": "mfma", "dwconv3x3": "hbm", "ss2d_scan": "hbm", "transpose_planes": "hbm"}
+_BOUND = {"gdmlp_fused": "mfma", "pw_gemm": "mfma", "conv2d": "mfma", "dwconv3x3": "hbm", "ss2d_scan": "hbm", "transpose_planes": "hbm"}
 
 
 def profile_start(kernel: str):

@@ -29,6 +29,7 @@ struct PwK {
     const float* res; const float* prelu; int act;
     float* out; int out_mode; int Win;
     int M; int K; int L; int KS; int MT;
+    int dbg;   // timing experiments (BEM_PW_DBG): bit0 skip MFMAs, bit1 skip epilogue
 };
 
 __device__ __forceinline__ float4 ld4(const float* __restrict__ row, int p, int L, bool vec) {
@@ -303,19 +304,18 @@ __global__ __launch_bounds__(256, 2) void pw_gemm2_kernel(PwK k, int kchunk) {
                             n1[u] = (w1 && sn < nks) ? w1[sn * 64] : 0.f;
                         }
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            if (s0 + u < nks) {
-                                const float4 xv = *reinterpret_cast<const float4*>(xs + (2 * (s0 + u) + half) * PT + 4 * j);
-                                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], xv.x, acc[0], 0, 0, 0);
-                                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], xv.y, acc[1], 0, 0, 0);
-                                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], xv.z, acc[2], 0, 0, 0);
-                                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], xv.w, acc[3], 0, 0, 0);
-                                if (w1) {
-                                    acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], xv.x, acc[4], 0, 0, 0);
-                                    acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], xv.y, acc[5], 0, 0, 0);
-                                    acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], xv.z, acc[6], 0, 0, 0);
-                                    acc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], xv.w, acc[7], 0, 0, 0);
-                                }
+                        for (int u = 0; u < 4; ++u) {      // branch-free: steps past the chunk pair zero weights with a valid LDS row
+                            const int krow = min(2 * (s0 + u) + half, kc - 1);
+                            const float4 xv = *reinterpret_cast<const float4*>(xs + krow * PT + 4 * j);
+                            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], xv.x, acc[0], 0, 0, 0);
+                            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], xv.y, acc[1], 0, 0, 0);
+                            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], xv.z, acc[2], 0, 0, 0);
+                            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], xv.w, acc[3], 0, 0, 0);
+                            if (w1) {
+                                acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], xv.x, acc[4], 0, 0, 0);
+                                acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], xv.y, acc[5], 0, 0, 0);
+                                acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], xv.z, acc[6], 0, 0, 0);
+                                acc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], xv.w, acc[7], 0, 0, 0);
                             }
                         }
 #pragma unroll
@@ -340,13 +340,11 @@ __global__ __launch_bounds__(256, 2) void pw_gemm2_kernel(PwK k, int kchunk) {
                             an[m][u] = (m < k.MT && sn < nks) ? w0[m * mt_stride + (int64_t)sn * 64] : 0.f;
                         }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if (s0 + u < nks) {
-                            const float xv = xs[(2 * (s0 + u) + half) * PT + 32 * wave + j];
+                    for (int u = 0; u < 4; ++u) {      // branch-free (zero weights past the chunk / past MT)
+                        const int krow = min(2 * (s0 + u) + half, kc - 1);
+                        const float xv = xs[krow * PT + 32 * wave + j];
 #pragma unroll
-                            for (int m = 0; m < 3; ++m)
-                                if (m < k.MT) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[m][u], xv, acc[m], 0, 0, 0);
-                        }
+                        for (int m = 0; m < 3; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[m][u], xv, acc[m], 0, 0, 0);
                     }
                 }
             }
@@ -566,22 +564,31 @@ __global__ __launch_bounds__(256, (KSM > 20 ? 1 : 2)) void pw_gemm3_reg_kernel(P
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][v][r] = 0.f;
         const float* wp = wbase + (int64_t)mt0 * mt_stride;
+        // No per-k-step branch: a branch makes every k-step its own basic block and pins each weight load right in
+        // front of its MFMAs (one L2 latency per step).  Steps beyond KS run on zero operands instead.
+        float av[KSM][MTW];
+#pragma unroll
+        for (int st = 0; st < KSM; ++st)
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) av[st][m] = (st < k.KS && mt0 + m < k.MT) ? wp[m * mt_stride + (int64_t)st * 64] : 0.f;
+        if (!(k.dbg & 1))
 #pragma unroll
         for (int st = 0; st < KSM; ++st) {
-            if (st < k.KS) {
-                float av[MTW];
 #pragma unroll
-                for (int m = 0; m < MTW; ++m) av[m] = (mt0 + m < k.MT) ? wp[m * mt_stride + (int64_t)st * 64] : 0.f;
-#pragma unroll
-                for (int m = 0; m < MTW; ++m) {
-                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], xr[st].x, acc[m][0], 0, 0, 0);
-                    acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], xr[st].y, acc[m][1], 0, 0, 0);
-                    acc[m][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], xr[st].z, acc[m][2], 0, 0, 0);
-                    acc[m][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], xr[st].w, acc[m][3], 0, 0, 0);
-                }
+            for (int m = 0; m < MTW; ++m) {
+                acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st][m], xr[st].x, acc[m][0], 0, 0, 0);
+                acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st][m], xr[st].y, acc[m][1], 0, 0, 0);
+                acc[m][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st][m], xr[st].z, acc[m][2], 0, 0, 0);
+                acc[m][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st][m], xr[st].w, acc[m][3], 0, 0, 0);
             }
         }
-        if (any) pw3_epilogue<MTW>(k, b, mt0, p, vec, half, acc);
+        if (any && !(k.dbg & 2)) pw3_epilogue<MTW>(k, b, mt0, p, vec, half, acc);
+        if (k.dbg & 2) { float sacc = 0.f;
+#pragma unroll
+            for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) sacc += acc[m][v][0] + acc[m][v][7] + acc[m][v][15];
+            if (sacc == 123.456f) k.out[0] = sacc; }
     }
 }
 
@@ -615,15 +622,13 @@ __global__ __launch_bounds__(256, 2) void pw_gemm3_stream_kernel(PwK k) {
     };
     auto mma_batch = [&](int s0, const float4 (&xb)[PF], const float (&ab)[MTW][PF]) {
 #pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            if (s0 + u < k.KS) {
+        for (int u = 0; u < PF; ++u) {      // steps beyond KS carry zero operands: no branch per step
 #pragma unroll
-                for (int m = 0; m < MTW; ++m) {
-                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[m][u], xb[u].x, acc[m][0], 0, 0, 0);
-                    acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[m][u], xb[u].y, acc[m][1], 0, 0, 0);
-                    acc[m][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[m][u], xb[u].z, acc[m][2], 0, 0, 0);
-                    acc[m][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[m][u], xb[u].w, acc[m][3], 0, 0, 0);
-                }
+            for (int m = 0; m < MTW; ++m) {
+                acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[m][u], xb[u].x, acc[m][0], 0, 0, 0);
+                acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[m][u], xb[u].y, acc[m][1], 0, 0, 0);
+                acc[m][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[m][u], xb[u].z, acc[m][2], 0, 0, 0);
+                acc[m][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[m][u], xb[u].w, acc[m][3], 0, 0, 0);
             }
         }
     };
@@ -685,6 +690,8 @@ extern "C" int bem_pw_gemm_f32(const bem_pw_args* a, void* stream) {
     k.Wp = a->Wp; k.w_bstride = a->w_bstride; k.bias = a->bias; k.bias_bstride = a->bias_bstride;
     k.res = a->res; k.prelu = a->prelu; k.act = a->act; k.out = a->out; k.out_mode = a->out_mode; k.Win = a->Win;
     k.M = a->M; k.K = a->K; k.L = a->L; k.KS = cdiv(a->K, 2); k.MT = cdiv(a->M, 32);
+    static int pw_dbg = getenv("BEM_PW_DBG") ? atoi(getenv("BEM_PW_DBG")) : 0;
+    k.dbg = pw_dbg;
     hipStream_t s = (hipStream_t)stream;
     const int Kp = 2 * k.KS;
     const bool ln = a->ln_w != nullptr;

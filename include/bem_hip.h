@@ -93,6 +93,25 @@ int bem_pack_pw_weight_f32(const float* W, float* Wp, int nsets, int M, int K, v
 int64_t bem_pw_packed_elems(int M, int K);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused gdMlp block (vmamba.py:116-133 + the norm2 / residual around it, vmamba.py:1330-1333):
+ *   out = x + Wo * (GELU(dw3x3(h)[0:Hd]) * dw3x3(h)[Hd:2Hd]) + bo,  h = Wi * LayerNorm_C(x) + bi
+ * x, out (B,C,H,W), C <= 160, Hd % 16 == 0, out != x.  Wpi: Wi (2Hd,C) packed by
+ * bem_pack_pw_weight_gate_f32 (gate rows regrouped per 16 channels); Wpo: Wo (C,Hd) packed by
+ * bem_pack_pw_weight_f32; dww (2Hd,9), dwb (2Hd) or NULL, bpi (2Hd), bpo (C) or NULL natural.
+ * *_bstride: elements between per-batch-element parameter sets (0 = shared).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* x; float* out;
+    const float* ln_w; const float* ln_b; float ln_eps;
+    const float* Wpi; int64_t wpi_bstride; const float* bpi; int64_t bpi_bstride;
+    const float* dww; int64_t dww_bstride; const float* dwb; int64_t dwb_bstride;
+    const float* Wpo; int64_t wpo_bstride; const float* bpo; int64_t bpo_bstride;
+    int B; int C; int Hd; int H; int W;
+} bem_gdmlp_args;
+int bem_gdmlp_fused_f32(const bem_gdmlp_args* a, void* stream);
+int bem_pack_pw_weight_gate_f32(const float* W, float* Wp, int nsets, int Hd, int K, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Convolutions.
  * ------------------------------------------------------------------------------------------- */
 /* Depthwise 3x3, padding 1 (vmamba.py:507-515 conv2d, :124 gdMlp.dwconv, QD/model4.py:157-165).

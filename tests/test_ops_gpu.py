@@ -331,3 +331,42 @@ def test_rejects_bad_arguments(ops):
         ops.pw_gemm(dev(x), ops.pack_pw_weight(dev(torch.randn(8, 5))), 8)
     with pytest.raises(BemNativeError):
         ops.conv2d(dev(x), dev(torch.randn(4, 4, 5, 5)), None, stride=1, pad=2)
+
+
+# ----------------------------------------------------------------------------- fused gdMlp ------
+@pytest.mark.parametrize("cfg", [(2, 40, 16, 12), (1, 16, 8, 8), (2, 8, 5, 7), (1, 80, 24, 33), (1, 160, 8, 8), (3, 40, 4, 4), (1, 40, 128, 128)])
+def test_gdmlp_fused_vs_oracle(ops, cfg):
+    """bem_gdmlp_fused_f32 (LN + project_in + dw3x3 + GELU gate + project_out + residual in one kernel)
+    vs oracle.gdmlp_ref on LN(x).  Tolerance 2e-4 rel / 5e-5 abs (two chained f32 GEMMs of depth C and 4C,
+    erf evaluated by the 1.5e-7-accurate A&S 7.1.26 form)."""
+    B, C, H, W = cfg
+    Hd = 4 * C
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(B, C, H, W, generator=g)
+    sd = {"project_in.weight": torch.randn(2 * Hd, C, 1, 1, generator=g) * C ** -0.5, "project_in.bias": 0.1 * torch.randn(2 * Hd, generator=g),
+          "dwconv.weight": torch.randn(2 * Hd, 1, 3, 3, generator=g) / 3, "dwconv.bias": 0.1 * torch.randn(2 * Hd, generator=g),
+          "project_out.weight": torch.randn(C, Hd, 1, 1, generator=g) * Hd ** -0.5, "project_out.bias": 0.1 * torch.randn(C, generator=g)}
+    lw, lb = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    ref = x + O.gdmlp_ref(sd, "", O.layernorm2d_ref(x, lw, lb))
+    Wpi = ops.pack_pw_weight_gate(dev(sd["project_in.weight"].reshape(2 * Hd, C)), Hd)
+    Wpo = ops.pack_pw_weight(dev(sd["project_out.weight"].reshape(C, Hd)))
+    y = ops.gdmlp_fused(dev(x), dev(lw), dev(lb), 1e-5, Wpi, dev(sd["project_in.bias"]), dev(sd["dwconv.weight"].reshape(2 * Hd, 9)),
+                        dev(sd["dwconv.bias"]), Wpo, dev(sd["project_out.bias"]), Hd)
+    close(y, ref, 2e-4, 5e-5, f"gdmlp fused {cfg}")
+
+
+def test_gdmlp_fused_per_batch_weights(ops):
+    B, C, H, W = 3, 16, 9, 10
+    Hd = 4 * C
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(B, C, H, W, generator=g)
+    wi, bi = torch.randn(B, 2 * Hd, C, generator=g) * 0.25, 0.1 * torch.randn(B, 2 * Hd, generator=g)
+    wd, bd = torch.randn(B, 2 * Hd, 1, 3, 3, generator=g) / 3, 0.1 * torch.randn(B, 2 * Hd, generator=g)
+    wo, bo = torch.randn(B, C, Hd, generator=g) * 0.1, 0.1 * torch.randn(B, C, generator=g)
+    lw, lb = torch.ones(C), torch.zeros(C)
+    ref = torch.cat([x[i:i + 1] + O.gdmlp_ref({"project_in.weight": wi[i][:, :, None, None], "project_in.bias": bi[i], "dwconv.weight": wd[i],
+                                               "dwconv.bias": bd[i], "project_out.weight": wo[i][:, :, None, None], "project_out.bias": bo[i]},
+                                              "", O.layernorm2d_ref(x[i:i + 1], lw, lb)) for i in range(B)])
+    y = ops.gdmlp_fused(dev(x), dev(lw), dev(lb), 1e-5, ops.pack_pw_weight_gate(dev(wi), Hd), dev(bi), dev(wd.reshape(B, 2 * Hd * 9)), dev(bd),
+                        ops.pack_pw_weight(dev(wo)), dev(bo), Hd)
+    close(y, ref, 2e-4, 5e-5, "gdmlp fused per-batch")
