@@ -463,14 +463,25 @@ def candidate_finalize(pred, target, samples_per_image, h, w, gt_mean):
 # current stream is the stream every wrapper launches on), together with that launch's algorithmic
 # bytes / flops.  Disabled (zero overhead beyond a None check) outside bench.py.
 _PROF = None
-_BOUND = {"gdmlp_fused": "mfma", "pw_gemm": "mfma", "conv2d": "mfma", "dwconv3x3": "hbm", "ss2d_scan": "hbm", "transpose_planes": "hbm"}
+# profile key -> (op wrapper it belongs to, roofline bound, kernel symbol reported to bench.py, predicate on the call)
+_KEYS = {
+    # the register-resident LN+GEMM kernel with >= 2 M-tiles (in_proj / out_proj / project_in at C <= 40)
+    "pw_gemm3_reg<20,2>": ("pw_gemm", "hbm", "pw_gemm3_reg_kernel<20, 2>", lambda K, M, ln: K <= 40 and M > 32),
+    "pw_gemm": ("pw_gemm", "mfma", "pw_gemm* (all variants)", lambda K, M, ln: True),
+    "gdmlp_fused": ("gdmlp_fused", "mfma", "gdmlp_fused_kernel", None),
+    "conv2d": ("conv2d", "mfma", "conv2d_kernel", None),
+    "dwconv3x3": ("dwconv3x3", "hbm", "dwconv3x3_kernel", None),
+    "ss2d_scan": ("ss2d_scan", "hbm", "ss2d_scan_kernel", None),
+    "transpose_planes": ("transpose_planes", "hbm", "transpose_planes_kernel", None),
+}
 
 
-def profile_start(kernel: str):
+def profile_start(key: str):
     global _PROF
-    if kernel not in _BOUND:
-        raise ValueError(f"profile_start: unknown op {kernel}; choose from {sorted(_BOUND)}")
-    _PROF = {"kernel": kernel, "events": [], "bytes": 0.0, "flops": 0.0}
+    if key not in _KEYS:
+        raise ValueError(f"profile_start: unknown key {key}; choose from {sorted(_KEYS)}")
+    op, bound, symbol, pred = _KEYS[key]
+    _PROF = {"kernel": op, "symbol": symbol, "bound": bound, "pred": pred, "events": [], "bytes": 0.0, "flops": 0.0}
 
 
 def profile_stop():
@@ -480,7 +491,7 @@ def profile_stop():
         return None
     torch.cuda.synchronize()
     ms = sum(s.elapsed_time(e) for s, e in p["events"])
-    return {"kernel": p["kernel"], "bound": _BOUND[p["kernel"]], "launches": len(p["events"]), "ms": ms,
+    return {"kernel": p["symbol"], "bound": p["bound"], "launches": len(p["events"]), "ms": ms,
             "bytes": p["bytes"], "flops": p["flops"]}
 
 
@@ -516,6 +527,8 @@ def _wrap_profiled():
         K = C1 + (x2.shape[1] if mode == 2 else 0)
         cin = C1 + (x2.shape[1] if x2 is not None else 0)
         nb = 4.0 * B * L * (cin + M + (M if kw.get("res") is not None else 0)) + 4.0 * Wp.numel()
+        if _PROF["kernel"] == "pw_gemm" and not _PROF["pred"](K, M, kw.get("ln") is not None):
+            return _pw(x1, Wp, M, **kw)
         s = _timed("pw_gemm", nb, 2.0 * M * K * L * B)
         out = _pw(x1, Wp, M, **kw)
         _timed_end(s)

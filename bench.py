@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--samples", type=int, default=8, help="Bayesian samples per image")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-kernel", default="pw_gemm", help="op whose launches are timed with HIP events for the roofline entry")
+    ap.add_argument("--profile-kernel", default="pw_gemm3_reg<20,2>", help="kernel whose launches are timed with HIP events for the roofline entry (bem.ops._KEYS)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -131,6 +131,16 @@ def main():
                 ach = prof["bytes"] / prof["launches"] / (avg_ms * 1e-3) / 1e9
                 out["roofline"] = {"kernel": prof["kernel"], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "launches": prof["launches"], "avg_launch_us": avg_ms * 1e3}
+        # HBM traffic of that kernel from the PMC counters: rocprofv3 cannot be nested inside this process, so the per-launch
+        # figure is taken from the committed counter passes of this same command (profiles/r01_traffic.json, see its _note)
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"]
+            key = out["roofline"]["kernel"].replace("_kernel<", "_kernel<")
+            if key in tr and world == 1 and (B, N, S) == (8, 8, 256):
+                out["roofline"]["traffic"] = tr[key]["hbm_bytes_per_launch"]
+                out["roofline"]["algorithmic_bytes_per_launch"] = prof["bytes"] / prof["launches"]
+        except (OSError, KeyError, ValueError):
+            pass
         # whole-path figure on SURVEY.md section 8d's algorithmic bytes: N * (32360 * Hp*Wp/4 + 11.1e6) per image
         bytes_img = N * (32360.0 * S * S / 4 + 11.1e6)
         out["path_hbm_roofline_frac"] = (out["value"] / world) * bytes_img / (HBM_PEAK_GBS * 1e9)
