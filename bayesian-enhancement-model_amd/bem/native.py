@@ -58,6 +58,7 @@ SIGNATURES = {
     "bem_pack_pw_weight_gate_f32": [P, P, I, I, I, P],
     "bem_dwconv3x3_f32": [P, P, I64, P, I64, P, I, I, I, I, I, P],
     "bem_conv2d_f32": [P, I64, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "bem_conv2d_mfma_f32": [P, I64, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "bem_quat_dwt_f32": [P, I64, P, I, I, I, P],
     "bem_dwt_f32": [P, P, I, I, I, I, P],
     "bem_iwt_f32": [P, P, I, I, I, I, P],

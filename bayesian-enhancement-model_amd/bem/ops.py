@@ -247,8 +247,25 @@ def dwconv3x3(x, w, bias=None, mode=0):
     return out
 
 
+_CONV_PACK = {}          # (data_ptr, version, shape) -> packed (Cout, Cin*KH*KW) weight for the MFMA conv
+USE_CONV_MFMA = __import__("os").environ.get("BEM_CONV_MFMA", "1") != "0"
+
+
+def _packed_conv_weight(w):
+    key = (w.data_ptr(), w._version, tuple(w.shape))
+    hit = _CONV_PACK.get(key)
+    if hit is None:
+        if len(_CONV_PACK) > 256:
+            _CONV_PACK.clear()
+        # the source tensor is kept alive with its packed copy: a freed-and-reused address must never alias a stale entry
+        hit = (w, pack_pw_weight(w.reshape(w.shape[0], -1).contiguous()))
+        _CONV_PACK[key] = hit
+    return hit[1]
+
+
 def conv2d(x, w, bias=None, stride=1, pad=1, relu=False, res1=None, res2=None, cin_slice=None):
-    """Dense conv.  ``cin_slice=(c0, Cin)`` convolves channels [c0, c0+Cin) of a wider contiguous x."""
+    """Dense conv.  ``cin_slice=(c0, Cin)`` convolves channels [c0, c0+Cin) of a wider contiguous x.
+    Runs as an implicit GEMM on the matrix cores (Cout <= 160), else on the direct VALU kernel."""
     _chk(x, "x"); _chk(w, "w"); _chk(bias, "bias", optional=True)
     _chk(res1, "res1", optional=True); _chk(res2, "res2", optional=True)
     B, Ct, H, W = x.shape
@@ -268,6 +285,10 @@ def conv2d(x, w, bias=None, stride=1, pad=1, relu=False, res1=None, res2=None, c
     if bias is not None and bias.shape != (Cout,):
         raise ValueError("conv2d: bias shape")
     xp = ctypes.c_void_p(x.data_ptr() + 4 * c0 * H * W)
+    if USE_CONV_MFMA and Cout <= 160 and ((KH, KW, stride) in ((3, 3, 1), (4, 4, 2))):
+        check(lib().bem_conv2d_mfma_f32(xp, Ct * H * W, _p(_packed_conv_weight(w)), _p(bias), _p(res1), _p(res2), _p(out), B, Cin, H, W,
+                                        Cout, KH, KW, stride, pad, int(relu), _stream()), "conv2d_mfma")
+        return out
     check(lib().bem_conv2d_f32(xp, Ct * H * W, _p(w), _p(bias), _p(res1), _p(res2), _p(out), B, Cin, H, W, Cout, KH, KW,
                                stride, pad, int(relu), _stream()), "conv2d")
     return out

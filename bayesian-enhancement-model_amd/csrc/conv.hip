@@ -173,6 +173,139 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const float* __restrict__ x
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// dense conv as an implicit GEMM on the f32 matrix cores.
+//   M = Cout (all M-tiles in every wave), N = output pixels, K = Cin*KH*KW in the weight tensor's own
+//   (ci, ky, kx) order, so the packed 1x1 operand layout (bem_pack_pw_weight_f32 on the (Cout, Cin*KH*KW) view)
+//   is the A operand.  One workgroup = 8 x 32 output pixels: wave w owns rows 2w, 2w+1 as two N-tiles.
+//   Input channels are streamed through LDS in chunks of CIB; a small LDS table maps k -> patch offset, so the
+//   B operand of k-step s is patch[offs[2s + lane/32] + row*S*PWP + (lane%32)*S].
+//   The k loop is branch-free (zero weights beyond K).
+// ------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int KH, int KW, int S, int MTW>
+__global__ __launch_bounds__(256) void conv2d_mfma_kernel(const float* __restrict__ x, int64_t x_bs,
+                                                          const float* __restrict__ Wp, const float* __restrict__ bias,
+                                                          const float* __restrict__ res1, const float* __restrict__ res2,
+                                                          float* __restrict__ out, int Cin, int H, int W, int Cout,
+                                                          int Ho, int Wo, int pad, int relu, int tilesX, int KS) {
+    constexpr int KK = KH * KW;
+    constexpr int KC = CIB * KK;                          // k values per chunk (even)
+    constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW, PWP = PW + 1;
+    __shared__ float patch[CIB * PH * PWP];
+    __shared__ int offs[KC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, j = lane & 31;
+    const int tile = blockIdx.x, b = blockIdx.y;
+    const int ty0 = (tile / tilesX) * TH, tx0 = (tile % tilesX) * TW;
+    const int iy0 = ty0 * S - pad, ix0 = tx0 * S - pad;
+    const float* xb = x + (int64_t)b * x_bs;
+    for (int i = threadIdx.x; i < KC; i += 256) {
+        const int cc = i / KK, t = i - cc * KK;
+        offs[i] = cc * PH * PWP + (t / KW) * PWP + (t % KW);
+    }
+    f32x16 acc[MTW][2];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+    const float* wl = Wp + lane;
+    const int64_t mts = (int64_t)KS * 64;
+    const int rowoff0 = (2 * wave) * S * PWP + j * S, rowoff1 = rowoff0 + S * PWP;
+
+    for (int ci0 = 0; ci0 < Cin; ci0 += CIB) {
+        __syncthreads();                                  // previous chunk fully consumed (also covers offs on the first pass)
+        {
+            constexpr int UB = 8;
+            constexpr int TOT = CIB * PH * PW;
+            for (int base = 0; base < TOT; base += 256 * UB) {
+                float v[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int i = base + u * 256 + threadIdx.x;
+                    const int cc = i / (PH * PW), rem = i - cc * (PH * PW);
+                    const int py = rem / PW, px = rem - py * PW;
+                    const int ci = ci0 + cc, iy = iy0 + py, ix = ix0 + px;
+                    v[u] = 0.f;
+                    if (i < TOT && ci < Cin && iy >= 0 && iy < H && ix >= 0 && ix < W) v[u] = xb[((int64_t)ci * H + iy) * W + ix];
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int i = base + u * 256 + threadIdx.x;
+                    if (i < TOT) {
+                        const int cc = i / (PH * PW), rem = i - cc * (PH * PW);
+                        const int py = rem / PW, px = rem - py * PW;
+                        patch[cc * PH * PWP + py * PWP + px] = v[u];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const int sg0 = (ci0 * KK) >> 1;                  // global k-step of this chunk's first step (CIB*KK is even)
+        constexpr int NS = KC / 2;                        // k-steps per chunk
+        constexpr int PB = 4;
+        static_assert(NS % PB == 0, "chunk k-steps must be a multiple of the operand batch");
+        float an[MTW][PB];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int u = 0; u < PB; ++u) an[m][u] = (sg0 + u < KS) ? wl[m * mts + (int64_t)(sg0 + u) * 64] : 0.f;
+        for (int s0 = 0; s0 < NS; s0 += PB) {
+            float ac[MTW][PB];
+#pragma unroll
+            for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                for (int u = 0; u < PB; ++u) {
+                    ac[m][u] = an[m][u];
+                    const int sn = sg0 + s0 + PB + u;
+                    an[m][u] = (s0 + PB + u < NS && sn < KS) ? wl[m * mts + (int64_t)sn * 64] : 0.f;
+                }
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                const int o = offs[2 * (s0 + u) + half];
+                const float v0 = patch[o + rowoff0], v1 = patch[o + rowoff1];
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) {
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[m][u], v0, acc[m][0], 0, 0, 0);
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[m][u], v1, acc[m][1], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // epilogue: out = relu?(acc + bias) + res1 + res2
+    const int ox = tx0 + j;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int oy = ty0 + 2 * wave + t;
+        if (oy >= Ho || ox >= Wo) continue;
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            float r1[16], r2[16], bv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int64_t idx = (((int64_t)b * Cout + co) * Ho + oy) * Wo + ox;
+                const bool ok = co < Cout;
+                bv[r] = (ok && bias) ? bias[co] : 0.f;
+                r1[r] = (ok && res1) ? res1[idx] : 0.f;
+                r2[r] = (ok && res2) ? res2[idx] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (co < Cout) {
+                    float v = acc[m][t][r] + bv[r];
+                    if (relu) v = fmaxf(v, 0.f);
+                    out[(((int64_t)b * Cout + co) * Ho + oy) * Wo + ox] = v + r1[r] + r2[r];
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int bem_dwconv3x3_f32(const float* x, const float* w, int64_t w_bstride, const float* bias,
@@ -205,4 +338,35 @@ extern "C" int bem_conv2d_f32(const float* x, int64_t x_bstride, const float* w,
     else
         BEM_REQUIRE(false, "conv2d: unsupported kernel %dx%d stride %d (have 3x3 s1, 4x4 s2)", KH, KW, stride);
     return bem_check_launch("conv2d");
+}
+
+extern "C" int bem_conv2d_mfma_f32(const float* x, int64_t x_bstride, const float* Wp, const float* bias,
+                                   const float* res1, const float* res2, float* out, int B, int Cin, int H, int W,
+                                   int Cout, int KH, int KW, int stride, int pad, int relu, void* stream) {
+    BEM_REQUIRE(x && Wp && out, "conv2d_mfma: null tensor");
+    BEM_REQUIRE(B >= 0 && B <= 65535 && Cin > 0 && Cout > 0 && Cout <= 160 && H > 0 && W > 0, "conv2d_mfma: bad shape (Cout <= 160)");
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    BEM_REQUIRE(Ho > 0 && Wo > 0, "conv2d_mfma: empty output");
+    if (B == 0) return BEM_OK;
+    const int tilesX = cdiv(Wo, TW), tilesY = cdiv(Ho, TH);
+    const int KS = cdiv(Cin * KH * KW, 2), MT = cdiv(Cout, 32);
+    dim3 grid(tilesX * tilesY, B);
+    hipStream_t s = (hipStream_t)stream;
+#define BEM_CONV_LAUNCH(KH_, KW_, S_, MTW_) \
+    conv2d_mfma_kernel<KH_, KW_, S_, MTW_><<<grid, 256, 0, s>>>(x, x_bstride, Wp, bias, res1, res2, out, Cin, H, W, Cout, Ho, Wo, pad, relu, tilesX, KS)
+    if (KH == 3 && KW == 3 && stride == 1) {
+        if (MT == 1) BEM_CONV_LAUNCH(3, 3, 1, 1);
+        else if (MT == 2) BEM_CONV_LAUNCH(3, 3, 1, 2);
+        else if (MT == 3) BEM_CONV_LAUNCH(3, 3, 1, 3);
+        else BEM_CONV_LAUNCH(3, 3, 1, 5);
+    } else if (KH == 4 && KW == 4 && stride == 2) {
+        if (MT == 1) BEM_CONV_LAUNCH(4, 4, 2, 1);
+        else if (MT == 2) BEM_CONV_LAUNCH(4, 4, 2, 2);
+        else if (MT == 3) BEM_CONV_LAUNCH(4, 4, 2, 3);
+        else BEM_CONV_LAUNCH(4, 4, 2, 5);
+    } else {
+        BEM_REQUIRE(false, "conv2d_mfma: unsupported kernel %dx%d stride %d (have 3x3 s1, 4x4 s2)", KH, KW, stride);
+    }
+#undef BEM_CONV_LAUNCH
+    return bem_check_launch("conv2d_mfma");
 }

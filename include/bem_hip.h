@@ -130,6 +130,12 @@ int bem_conv2d_f32(const float* x, int64_t x_bstride, const float* w, const floa
                    const float* res2, float* out, int B, int Cin, int H, int W, int Cout, int KH, int KW,
                    int stride, int pad, int relu, void* stream);
 
+/* The same convolution as an implicit GEMM on the f32 matrix cores; Wp = the (Cout, Cin*KH*KW) view of the weight
+ * packed by bem_pack_pw_weight_f32.  Cout <= 160; 3x3 stride 1 and 4x4 stride 2. */
+int bem_conv2d_mfma_f32(const float* x, int64_t x_bstride, const float* Wp, const float* bias, const float* res1,
+                        const float* res2, float* out, int B, int Cin, int H, int W, int Cout, int KH, int KW,
+                        int stride, int pad, int relu, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Quaternion / Haar primitives (basicsr/QD/model4.py:7-37,216-232; QD/quaternion.py:3-17).
  * ------------------------------------------------------------------------------------------- */
