@@ -252,7 +252,8 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(const float* __restric
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
-            for (int u = 0; u < PB; ++u) an[m][u] = (sg0 + u < KS) ? wl[m * mts + (int64_t)(sg0 + u) * 64] : 0.f;
+            for (int u = 0; u < PB; ++u)      // clamped address, masked by multiplication (a uniform select becomes a branch + vmcnt(0))
+                an[m][u] = wl[m * mts + (int64_t)min(sg0 + u, KS - 1) * 64] * ((sg0 + u < KS) ? 1.f : 0.f);
         for (int s0 = 0; s0 < NS; s0 += PB) {
             float ac[MTW][PB];
 #pragma unroll
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(const float* __restric
                 for (int u = 0; u < PB; ++u) {
                     ac[m][u] = an[m][u];
                     const int sn = sg0 + s0 + PB + u;
-                    an[m][u] = (s0 + PB + u < NS && sn < KS) ? wl[m * mts + (int64_t)sn * 64] : 0.f;
+                    an[m][u] = wl[m * mts + (int64_t)min(sn, KS - 1) * 64] * ((s0 + PB + u < NS && sn < KS) ? 1.f : 0.f);
                 }
 #pragma unroll
             for (int u = 0; u < PB; ++u) {

@@ -178,9 +178,9 @@ __global__ __launch_bounds__(256, 2) void gdmlp_fused_kernel(GdK k) {
     // loop needs no per-step branch (a branch per k-step costs more than the wasted MFMA issue slots).
     auto load_a = [&](int g, float (&dst)[PB]) {
         const int cg = g / nb, s0 = (g - cg * nb) * PB;
-        const float* wa = wpi + (int64_t)cg * k.KS * 64;
 #pragma unroll
-        for (int u = 0; u < PB; ++u) dst[u] = (g < total_b && s0 + u < k.KS) ? wa[(s0 + u) * 64] : 0.f;
+        for (int u = 0; u < PB; ++u)        // clamped address + multiplicative mask (uniform selects turn into branch + vmcnt(0))
+            dst[u] = wpi[((int64_t)min(cg, nchunks - 1) * k.KS + min(s0 + u, k.KS - 1)) * 64] * ((g < total_b && s0 + u < k.KS) ? 1.f : 0.f);
     };
     float a_n0[PB], a_n1[PB];
     load_a(0, a_n0);
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void gdmlp_fused_kernel(GdK k) {
 #pragma unroll
             for (int s = 0; s < 8; ++s)
 #pragma unroll
-                for (int m = 0; m < MTO_MAX; ++m) a3[s][m] = (m < k.MTo) ? wo[m * mts + s * 64] : 0.f;
+                for (int m = 0; m < MTO_MAX; ++m) a3[s][m] = wo[(m < k.MTo ? m : 0) * mts + s * 64] * ((m < k.MTo) ? 1.f : 0.f);
         }
         __syncthreads();
         GD_STAMP(4 + 5 * ch);

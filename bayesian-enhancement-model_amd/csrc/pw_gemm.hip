@@ -56,6 +56,59 @@ __device__ __forceinline__ float4 load_x(const PwK& k, int b, int ch, int p, boo
     return v;
 }
 
+// ---- branch-free input fetch -------------------------------------------------------------------------------
+// load_x above nests data-dependent branches (concat / sum / tail handling); inside an unrolled loop hipcc then
+// emits every load in its own basic block followed by s_waitcnt vmcnt(0), i.e. one full memory latency PER LOAD.
+// The forms below always load from a clamped, valid address and select the value afterwards, so an unrolled
+// loop of them is a straight run of loads with a single wait.  SUM (x1 + x2) is a compile-time variant; concat
+// is a pointer select.  `pc` must be a valid pixel index of the plane for every lane (clamp before calling).
+template <bool SUM>
+__device__ __forceinline__ float4 ldx4(const PwK& k, int b, int ch, int pc, bool keep) {
+    const int chc = min(ch, k.K - 1);
+    const bool first = chc < k.C1;
+    const float* r1 = k.x1 + ((int64_t)b * k.C1 + (first ? chc : 0)) * k.L;
+    const float* r2 = k.x2 + ((int64_t)b * k.C2 + (first ? 0 : chc - k.C1)) * k.L;
+    const float* base = first ? r1 : r2;
+    float4 v = *reinterpret_cast<const float4*>(base + pc);
+    if (SUM) {
+        const float4 w = *reinterpret_cast<const float4*>(k.x2 + ((int64_t)b * k.C2 + chc) * k.L + pc);
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    const bool m = keep && ch < k.K;
+    v.x = m ? v.x : 0.f; v.y = m ? v.y : 0.f; v.z = m ? v.z : 0.f; v.w = m ? v.w : 0.f;
+    return v;
+}
+// scalar form for planes whose length is not a multiple of 4 (rows are then unaligned): 4 clamped scalar loads
+template <bool SUM>
+__device__ __forceinline__ float4 ldx1(const PwK& k, int b, int ch, int p, bool keep) {
+    const int chc = min(ch, k.K - 1);
+    const bool first = chc < k.C1;
+    const float* r1 = k.x1 + ((int64_t)b * k.C1 + (first ? chc : 0)) * k.L;
+    const float* r2 = k.x2 + ((int64_t)b * k.C2 + (first ? 0 : chc - k.C1)) * k.L;
+    const float* base = first ? r1 : r2;
+    const float* sec = k.x2 + ((int64_t)b * k.C2 + chc) * k.L;
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pi = min(p + i, k.L - 1);
+        float v = base[pi];
+        if (SUM) v += sec[pi];
+        o[i] = (keep && ch < k.K && p + i < k.L) ? v : 0.f;
+    }
+    return make_float4(o[0], o[1], o[2], o[3]);
+}
+// fills xr[0..N) with the k-steps s0, s0+1, ... of this lane (channel 2s + half).  VEC / SUM are compile-time: a
+// uniform runtime branch around the loads would still end in a block join where hipcc waits vmcnt(0).
+template <int N, bool VEC, bool SUM>
+__device__ __forceinline__ void load_steps(const PwK& k, int b, int s0, int half, int p, bool any, float4 (&xr)[N]) {
+    const int pc = any ? p : 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        if (VEC) xr[i] = ldx4<SUM>(k, b, 2 * (s0 + i) + half, pc, any);
+        else xr[i] = ldx1<SUM>(k, b, 2 * (s0 + i) + half, pc, any);
+    }
+}
+
 template <int MTW>
 __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(PwK k) {
     const int lane = threadIdx.x & 63;
@@ -201,6 +254,7 @@ __device__ __forceinline__ void pw2_stage(const PwK& k, float* xs, int b, int p0
     // UB float4 per thread before anything is written to LDS, so a batch costs one memory latency.
     constexpr int UB = 8;
     const int total = kc * (PT / 4);
+    const bool sum = k.in_mode == 1;
     for (int base = 0; base < total; base += 256 * UB) {
         float4 v[UB];
 #pragma unroll
@@ -208,8 +262,10 @@ __device__ __forceinline__ void pw2_stage(const PwK& k, float* xs, int b, int p0
             const int idx = base + u * 256 + threadIdx.x;
             const int cc = idx / (PT / 4), p4 = idx - cc * (PT / 4);
             const int p = p0 + 4 * p4;
-            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < total && p < k.L) v[u] = load_x(k, b, c0 + cc, p, vecL && (p + 3 < k.L));
+            const bool keep = idx < total && p < k.L;
+            const int ch = keep ? c0 + cc : 0, pc = keep ? p : 0;
+            if (vecL) v[u] = sum ? ldx4<true>(k, b, ch, pc, keep) : ldx4<false>(k, b, ch, pc, keep);
+            else v[u] = sum ? ldx1<true>(k, b, ch, pc, keep) : ldx1<false>(k, b, ch, pc, keep);
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
@@ -290,18 +346,24 @@ __global__ __launch_bounds__(256, 2) void pw_gemm2_kernel(PwK k, int kchunk) {
                 const float* w1 = (mts[1] < k.MT) ? wbase + mts[1] * mt_stride + (int64_t)ks0 * 64 : nullptr;
                 if (w0) {
                     float a0[4], a1[4];
+                    const float* w1s = w1 ? w1 : w0;              // valid address either way; masked by multiplication
+                    const float m1 = w1 ? 1.f : 0.f;
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        a0[u] = (u < nks) ? w0[u * 64] : 0.f;
-                        a1[u] = (w1 && u < nks) ? w1[u * 64] : 0.f;
+                        const int uc = min(u, nks - 1);
+                        const float mk = (u < nks) ? 1.f : 0.f;
+                        a0[u] = w0[uc * 64] * mk;
+                        a1[u] = w1s[uc * 64] * (mk * m1);
                     }
                     for (int s0 = 0; s0 < nks; s0 += 4) {
                         float n0[4], n1[4];
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const int sn = s0 + 4 + u;
-                            n0[u] = (sn < nks) ? w0[sn * 64] : 0.f;
-                            n1[u] = (w1 && sn < nks) ? w1[sn * 64] : 0.f;
+                            const int sc = min(sn, nks - 1);
+                            const float mk = (sn < nks) ? 1.f : 0.f;
+                            n0[u] = w0[sc * 64] * mk;
+                            n1[u] = w1s[sc * 64] * (mk * m1);
                         }
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {      // branch-free: steps past the chunk pair zero weights with a valid LDS row
@@ -328,7 +390,8 @@ __global__ __launch_bounds__(256, 2) void pw_gemm2_kernel(PwK k, int kchunk) {
 #pragma unroll
                 for (int m = 0; m < 3; ++m)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) an[m][u] = (m < k.MT && u < nks) ? w0[m * mt_stride + (int64_t)u * 64] : 0.f;
+                    for (int u = 0; u < 4; ++u)
+                        an[m][u] = w0[(m < k.MT ? m : 0) * mt_stride + (int64_t)min(u, nks - 1) * 64] * ((m < k.MT && u < nks) ? 1.f : 0.f);
                 for (int s0 = 0; s0 < nks; s0 += 4) {
                     float ac[3][4];
 #pragma unroll
@@ -337,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm2_kernel(PwK k, int kchunk) {
                         for (int u = 0; u < 4; ++u) {
                             ac[m][u] = an[m][u];
                             const int sn = s0 + 4 + u;
-                            an[m][u] = (m < k.MT && sn < nks) ? w0[m * mt_stride + (int64_t)sn * 64] : 0.f;
+                            an[m][u] = w0[(m < k.MT ? m : 0) * mt_stride + (int64_t)min(sn, nks - 1) * 64] * ((m < k.MT && sn < nks) ? 1.f : 0.f);
                         }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {      // branch-free (zero weights past the chunk / past MT)
@@ -509,7 +572,7 @@ __device__ __forceinline__ void pw3_epilogue(const PwK& k, int b, int mt0, int p
     }
 }
 
-template <int KSM, int MTW>
+template <int KSM, int MTW, bool VEC, bool SUM>
 __global__ __launch_bounds__(256, (KSM > 20 ? 1 : 2)) void pw_gemm3_reg_kernel(PwK k) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
     const int b = blockIdx.z;
@@ -518,9 +581,7 @@ __global__ __launch_bounds__(256, (KSM > 20 ? 1 : 2)) void pw_gemm3_reg_kernel(P
     const bool vec = (k.L % 4 == 0) && (p + 3 < k.L);
     const bool any = p < k.L;
     float4 xr[KSM];
-#pragma unroll
-    for (int st = 0; st < KSM; ++st)
-        xr[st] = (any && st < k.KS) ? load_x(k, b, 2 * st + half, p, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+    load_steps<KSM, VEC, SUM>(k, b, 0, half, p, any, xr);      // channels >= K come back as zeros
     if (k.ln_w) {
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -564,23 +625,39 @@ __global__ __launch_bounds__(256, (KSM > 20 ? 1 : 2)) void pw_gemm3_reg_kernel(P
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][v][r] = 0.f;
         const float* wp = wbase + (int64_t)mt0 * mt_stride;
-        // No per-k-step branch: a branch makes every k-step its own basic block and pins each weight load right in
-        // front of its MFMAs (one L2 latency per step).  Steps beyond KS run on zero operands instead.
-        float av[KSM][MTW];
+        // No per-k-step branch (each would be its own basic block with the weight load pinned in front of its MFMAs);
+        // steps beyond KS run on zero operands.  Weights arrive in batches of AB k-steps, one batch ahead.
+        constexpr int AB = 5;
+        static_assert(KSM % AB == 0, "KSM must be a multiple of the weight batch");
+        auto load_w = [&](int sb, float (&dst)[AB][MTW]) {
 #pragma unroll
-        for (int st = 0; st < KSM; ++st)
+            for (int u = 0; u < AB; ++u)
 #pragma unroll
-            for (int m = 0; m < MTW; ++m) av[st][m] = (st < k.KS && mt0 + m < k.MT) ? wp[m * mt_stride + (int64_t)st * 64] : 0.f;
+                for (int m = 0; m < MTW; ++m) {
+                    const float w = wp[(mt0 + m < k.MT ? m : 0) * mt_stride + (int64_t)min(sb + u, k.KS - 1) * 64];   // valid address
+                    dst[u][m] = w * ((sb + u < k.KS && mt0 + m < k.MT) ? 1.f : 0.f);    // multiply, not select (see stream kernel)
+                }
+        };
+        float avn[AB][MTW];
+        load_w(0, avn);
         if (!(k.dbg & 1))
 #pragma unroll
-        for (int st = 0; st < KSM; ++st) {
+        for (int sb = 0; sb < KSM; sb += AB) {
+            float avc[AB][MTW];
 #pragma unroll
-            for (int m = 0; m < MTW; ++m) {
-                acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st][m], xr[st].x, acc[m][0], 0, 0, 0);
-                acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st][m], xr[st].y, acc[m][1], 0, 0, 0);
-                acc[m][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st][m], xr[st].z, acc[m][2], 0, 0, 0);
-                acc[m][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st][m], xr[st].w, acc[m][3], 0, 0, 0);
-            }
+            for (int u = 0; u < AB; ++u)
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) avc[u][m] = avn[u][m];
+            if (sb + AB < KSM) load_w(sb + AB, avn);
+#pragma unroll
+            for (int u = 0; u < AB; ++u)
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) {
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(avc[u][m], xr[sb + u].x, acc[m][0], 0, 0, 0);
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(avc[u][m], xr[sb + u].y, acc[m][1], 0, 0, 0);
+                    acc[m][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(avc[u][m], xr[sb + u].z, acc[m][2], 0, 0, 0);
+                    acc[m][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(avc[u][m], xr[sb + u].w, acc[m][3], 0, 0, 0);
+                }
         }
         if (any && !(k.dbg & 2)) pw3_epilogue<MTW>(k, b, mt0, p, vec, half, acc);
         if (k.dbg & 2) { float sacc = 0.f;
@@ -592,9 +669,9 @@ __global__ __launch_bounds__(256, (KSM > 20 ? 1 : 2)) void pw_gemm3_reg_kernel(P
     }
 }
 
-template <int MTW>
+template <int MTW, bool VEC, bool SUM>
 __global__ __launch_bounds__(256, 2) void pw_gemm3_stream_kernel(PwK k) {
-    constexpr int PF = 4;   // k-steps per batch; two register batches alternate (load one, multiply the other)
+    constexpr int PF = 4;   // k-steps per batch
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
     const int b = blockIdx.z;
     const int mt0 = blockIdx.y * MTW;
@@ -612,12 +689,18 @@ __global__ __launch_bounds__(256, 2) void pw_gemm3_stream_kernel(PwK k) {
     const float* wp = k.Wp + (int64_t)b * k.w_bstride + ((int64_t)mt0 * k.KS) * 64 + lane;
     const int64_t mt_stride = (int64_t)k.KS * 64;
     auto load_batch = [&](int s0, float4 (&xb)[PF], float (&ab)[MTW][PF]) {
+        load_steps<PF, VEC, SUM>(k, b, s0, half, p, any, xb);       // branch-free; steps past K give zeros
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             const int sn = s0 + u;
-            xb[u] = (any && sn < k.KS) ? load_x(k, b, 2 * sn + half, p, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int sc = min(sn, k.KS - 1);                        // clamped address, value selected
 #pragma unroll
-            for (int m = 0; m < MTW; ++m) ab[m][u] = (mt0 + m < k.MT && sn < k.KS) ? wp[m * mt_stride + (int64_t)sn * 64] : 0.f;
+            for (int m = 0; m < MTW; ++m) {
+                // valid address always; masked by MULTIPLYING: a select on this wave-uniform condition is turned back into a
+                // branch around the load by hipcc, and every such block ends in s_waitcnt vmcnt(0)
+                const float w = wp[(mt0 + m < k.MT ? m : 0) * mt_stride + (int64_t)sc * 64];
+                ab[m][u] = w * ((mt0 + m < k.MT && sn < k.KS) ? 1.f : 0.f);
+            }
         }
     };
     auto mma_batch = [&](int s0, const float4 (&xb)[PF], const float (&ab)[MTW][PF]) {
@@ -632,14 +715,19 @@ __global__ __launch_bounds__(256, 2) void pw_gemm3_stream_kernel(PwK k) {
             }
         }
     };
-    float4 xA[PF], xB[PF];
-    float aA[MTW][PF], aB[MTW][PF];
+    // three register batches rotate: two are always in flight behind the one being multiplied (one batch = 4 k-steps =
+    // 32 MFMAs ~ 0.9 us of matrix-core time, less than a loaded HBM round trip, so a single batch ahead still stalls)
+    float4 xA[PF], xB[PF], xC[PF];
+    float aA[MTW][PF], aB[MTW][PF], aC[MTW][PF];
     load_batch(0, xA, aA);
-    for (int s0 = 0; s0 < k.KS; s0 += 2 * PF) {
-        load_batch(s0 + PF, xB, aB);
+    load_batch(PF, xB, aB);
+    for (int s0 = 0; s0 < k.KS; s0 += 3 * PF) {
+        load_batch(s0 + 2 * PF, xC, aC);
         mma_batch(s0, xA, aA);
-        load_batch(s0 + 2 * PF, xA, aA);
+        load_batch(s0 + 3 * PF, xA, aA);
         mma_batch(s0 + PF, xB, aB);
+        load_batch(s0 + 4 * PF, xB, aB);
+        mma_batch(s0 + 2 * PF, xC, aC);
     }
     if (any) pw3_epilogue<MTW>(k, b, mt0, p, vec, half, acc);
 }
@@ -699,20 +787,29 @@ extern "C" int bem_pw_gemm_f32(const bem_pw_args* a, void* stream) {
     if (!force_v1) {
         // v3: barrier-free.  Register-resident input for K <= 80 (LayerNorm or not), software-pipelined stream otherwise.
         dim3 grid(cdiv(a->L, 512), 1, a->B);
+        const bool vecL = (a->L % 4 == 0), sum = (a->in_mode == 1);
+#define BEM_PW_VS(KERNEL, ...)                                                     \
+    do {                                                                           \
+        if (vecL && !sum) KERNEL<__VA_ARGS__, true, false><<<grid, 256, 0, s>>>(k);     \
+        else if (vecL && sum) KERNEL<__VA_ARGS__, true, true><<<grid, 256, 0, s>>>(k); \
+        else if (!sum) KERNEL<__VA_ARGS__, false, false><<<grid, 256, 0, s>>>(k);       \
+        else KERNEL<__VA_ARGS__, false, true><<<grid, 256, 0, s>>>(k);                  \
+    } while (0)
         if (k.KS <= 20) {
-            if (k.MT == 1) pw_gemm3_reg_kernel<20, 1><<<grid, 256, 0, s>>>(k);
-            else pw_gemm3_reg_kernel<20, 2><<<grid, 256, 0, s>>>(k);
+            if (k.MT == 1) BEM_PW_VS(pw_gemm3_reg_kernel, 20, 1);
+            else BEM_PW_VS(pw_gemm3_reg_kernel, 20, 2);
             return bem_check_launch("pw_gemm3_reg");
         }
         if (!ln) {
             if (k.MT == 1) {
-                pw_gemm3_stream_kernel<1><<<grid, 256, 0, s>>>(k);
+                BEM_PW_VS(pw_gemm3_stream_kernel, 1);
             } else {
                 grid.y = cdiv(k.MT, 2);
-                pw_gemm3_stream_kernel<2><<<grid, 256, 0, s>>>(k);
+                BEM_PW_VS(pw_gemm3_stream_kernel, 2);
             }
             return bem_check_launch("pw_gemm3_stream");
         }
+#undef BEM_PW_VS
     }
     if (force_v1 != 1 && !(ln && Kp > 160)) {
         // v2: LDS-staged.  LayerNorm needs the whole K in LDS (<= 160 channels = 80 KiB); otherwise stream KCH-channel chunks.
