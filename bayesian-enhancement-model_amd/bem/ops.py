@@ -487,8 +487,9 @@ _PROF = None
 # profile key -> (op wrapper it belongs to, roofline bound, kernel symbol reported to bench.py, predicate on the call)
 _KEYS = {
     # the register-resident LN+GEMM kernel with >= 2 M-tiles (in_proj / out_proj / project_in at C <= 40)
-    "pw_gemm3_reg<20,2>": ("pw_gemm", "hbm", "pw_gemm3_reg_kernel<20, 2>", lambda K, M, ln: K <= 40 and M > 32),
-    "pw_gemm": ("pw_gemm", "mfma", "pw_gemm* (all variants)", lambda K, M, ln: True),
+    # (vectorised, single-input form: L % 4 == 0, in_mode 0 or 2 -- the variant every level-0 in_proj / project_in runs)
+    "pw_gemm3_reg<20,2>": ("pw_gemm", "hbm", "pw_gemm3_reg_kernel<20, 2, true, false>", lambda K, M, ln, L, mode: K <= 40 and M > 32 and L % 4 == 0 and mode != 1),
+    "pw_gemm": ("pw_gemm", "mfma", "pw_gemm* (all variants)", lambda K, M, ln, L, mode: True),
     "gdmlp_fused": ("gdmlp_fused", "mfma", "gdmlp_fused_kernel", None),
     "conv2d": ("conv2d", "mfma", "conv2d_kernel", None),
     "dwconv3x3": ("dwconv3x3", "hbm", "dwconv3x3_kernel", None),
@@ -548,7 +549,7 @@ def _wrap_profiled():
         K = C1 + (x2.shape[1] if mode == 2 else 0)
         cin = C1 + (x2.shape[1] if x2 is not None else 0)
         nb = 4.0 * B * L * (cin + M + (M if kw.get("res") is not None else 0)) + 4.0 * Wp.numel()
-        if _PROF["kernel"] == "pw_gemm" and not _PROF["pred"](K, M, kw.get("ln") is not None):
+        if _PROF["kernel"] == "pw_gemm" and not _PROF["pred"](K, M, kw.get("ln") is not None, L, mode):
             return _pw(x1, Wp, M, **kw)
         s = _timed("pw_gemm", nb, 2.0 * M * K * L * B)
         out = _pw(x1, Wp, M, **kw)
