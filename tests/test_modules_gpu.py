@@ -173,3 +173,23 @@ def test_eval_loop_golden_g8():
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
+
+
+def test_stage2_config5_geometry_400x600():
+    """BASELINE config-5 geometry: a 400x600 image is reflect-padded to 448x640 (L = 71680 at level 0: multi-chunk scan
+    with the global read-modify-write path, non-square maps, 28x40 condition).  One (image, sample) pair, seeded weights,
+    deterministic Stage-I: HIP pipeline vs the CPU oracle; PSNR of the candidate must agree within 1e-3 dB."""
+    from bem.pipeline import BEMPipeline, build_nets, synthetic_pair
+    net1, net2 = build_nets(device="cuda")
+    sd1 = {k: v.detach().cpu() for k, v in net1.state_dict().items()}
+    sd2 = {k: v.detach().cpu() for k, v in net2.state_dict().items()}
+    lq, gt = synthetic_pair((1, 3, 400, 600), seed=5)
+    noise = torch.randn(1, 3, 28, 40, generator=torch.Generator().manual_seed(9))
+    ref = O.eval_mc_ref(sd1, sd2, lq, gt, 1, deterministic=True, gt_mean=True, noise_list=[noise], scan=O.selective_scan_c)
+    out = BEMPipeline(net1, net2).enhance(lq.cuda(), gt.cuda(), 1, gt_mean=True, deterministic=True, noise=noise.cuda())
+    assert out["raw"].shape == (1, 3, 448, 640) and out["final"].shape == (1, 3, 400, 600)
+    # raw candidate (before the GT-mean rescale, whose ratio ~ 20x on these random-init nets amplifies differences)
+    close(out["raw"][:, :, :400, :600].clamp(0, 1), ref["preds"][0], 2e-3, 5e-4, "config-5 geometry raw candidate")
+    d = (out["final"][0].permute(1, 2, 0).cpu() - torch.from_numpy(ref["finals"][0])).abs()
+    assert d.mean() < 1e-5 and d.max() < 2e-2, (d.mean(), d.max())
+    assert abs(float(out["psnr"][0]) - ref["psnr"][0]) < 1e-3
