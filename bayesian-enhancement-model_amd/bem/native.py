@@ -48,6 +48,8 @@ P, I, I64, U64, F = c_void_p, c_int, c_int64, c_uint64, c_float
 # "every declared symbol is exported" CPU test checks against include/bem_hip.h.
 SIGNATURES = {
     "bem_selective_scan_fwd_f32": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, P],
+    "bem_selective_scan_bwd_ws_elems": [I, I, I, I],
+    "bem_selective_scan_bwd_f32": [P] * 16 + [I, I, I, I, I, I, P],
     "bem_cross_scan_f32": [P, P, I, I, I, I, P],
     "bem_cross_merge_f32": [P, P, I, I, I, I, P],
     "bem_ss2d_scan_f32": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
@@ -78,7 +80,7 @@ SIGNATURES = {
     "bem_last_error": [],
     "bem_abi_version": [],
 }
-_RESTYPE = {"bem_last_error": ctypes.c_char_p, "bem_pw_packed_elems": c_int64}
+_RESTYPE = {"bem_last_error": ctypes.c_char_p, "bem_pw_packed_elems": c_int64, "bem_selective_scan_bwd_ws_elems": c_int64}
 
 _lib = None
 

@@ -61,6 +61,26 @@ def selective_scan_fwd(u, delta, A, B, C, D=None, delta_bias=None, delta_softplu
     return out
 
 
+def selective_scan_bwd(u, delta, A, B, C, D, delta_bias, dout, delta_softplus=True):
+    """Gradients (du, ddelta, dA, dB, dC, dD|None, ddelta_bias|None) of selective_scan_fwd w.r.t. its inputs."""
+    for n, t in (("u", u), ("delta", delta), ("A", A), ("B", B), ("C", C), ("dout", dout)):
+        _chk(t, n)
+    _chk(D, "D", optional=True); _chk(delta_bias, "delta_bias", optional=True)
+    Bt, KC, L = u.shape
+    K, N = B.shape[1], B.shape[2]
+    if delta.shape != u.shape or dout.shape != u.shape or A.shape != (KC, N) or C.shape != B.shape or B.shape[0] != Bt or B.shape[3] != L or KC % K:
+        raise ValueError("selective_scan_bwd: shapes")
+    du, dd = torch.empty_like(u), torch.empty_like(u)
+    dA, dB, dC = torch.empty_like(A), torch.empty_like(B), torch.empty_like(C)
+    dD = torch.empty_like(D) if D is not None else None
+    db = torch.empty_like(delta_bias) if delta_bias is not None else None
+    ws = torch.empty(int(lib().bem_selective_scan_bwd_ws_elems(Bt, KC, L, N)), device=u.device, dtype=torch.float32)
+    check(lib().bem_selective_scan_bwd_f32(_p(u), _p(delta), _p(A), _p(B), _p(C), _p(D), _p(delta_bias), _p(dout), _p(ws), _p(du), _p(dd),
+                                           _p(dA), _p(dB), _p(dC), _p(dD), _p(db), Bt, KC, L, N, K, int(bool(delta_softplus)), _stream()),
+          "selective_scan_bwd")
+    return du, dd, dA, dB, dC, dD, db
+
+
 def cross_scan(x):
     _chk(x, "x")
     B, C, H, W = x.shape

@@ -163,6 +163,166 @@ __global__ __launch_bounds__(NT) void selective_scan_fwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// General selective scan, backward (replaces selective_scan_cuda_oflex.bwd, selective_scan_bwd_kernel_oflex.cuh:73-289).
+// One workgroup per (batch, channel) row.
+//   pass 1 (chunks ascending)  recompute the forward states, keep the state entering every chunk in `ws`
+//   pass 2 (chunks descending) per chunk and state n: rebuild h_t from the saved carry (forward block scan), then
+//           dh_t = C_t dy_t + a_{t+1} dh_{t+1} by the mirrored (reverse) block scan, then
+//             du_t   = D dy_t + sum_n dh dt B            ddt_t = sum_n dh (B u + A (h - dt B u))
+//             dB_t,n += dh dt u  , dC_t,n += dy h        (atomics: shared by the channels of a group, like the reference)
+//             dA_n  += dh dt (h - dt B u)                dD += dy u
+//           ddelta_t = ddt_t * sigmoid(delta + bias) (softplus), ddelta_bias += ddelta_t
+// a_{t+1} of a thread's last element is recomputed from delta[t+1] (one extra exp per thread) instead of being
+// exchanged between lanes.
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ float block_reduce_sum(float v, float* sh) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, BEM_WAVE);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT / BEM_WAVE; ++w) s += sh[w];
+    return s;
+}
+
+template <int NT, int E>
+__global__ __launch_bounds__(NT) void selective_scan_bwd_kernel(
+    const float* __restrict__ u, const float* __restrict__ delta, const float* __restrict__ A,
+    const float* __restrict__ Bm, const float* __restrict__ Cm, const float* __restrict__ D,
+    const float* __restrict__ dbias, const float* __restrict__ dout, float* __restrict__ ws,
+    float* __restrict__ du, float* __restrict__ ddelta, float* __restrict__ dA, float* __restrict__ dB,
+    float* __restrict__ dC, float* __restrict__ dD, float* __restrict__ ddbias, int dim, int L, int dstate,
+    int ngroups, int softplus) {
+    __shared__ float agg[2 * (NT / BEM_WAVE)];
+    __shared__ float red[NT / BEM_WAVE];
+    __shared__ float carry_s[256];
+    const int d = blockIdx.x, b = blockIdx.y;
+    const int g = d / (dim / ngroups);
+    const int64_t row = ((int64_t)b * dim + d) * L;
+    const float* ur = u + row;
+    const float* dr = delta + row;
+    const float* gr = dout + row;
+    const float bias = dbias ? dbias[d] : 0.f;
+    const float Dd = D ? D[d] : 0.f;
+    const bool vec = (L % 4 == 0);
+    constexpr int CH = NT * E;
+    const int nchunks = (L + CH - 1) / CH;
+    float* wsr = ws + ((int64_t)b * dim + d) * nchunks * dstate;
+
+    auto dt_of = [&](float dl) { dl += bias; return softplus ? bem_softplus(dl) : dl; };
+
+    // ---- pass 1: state entering every chunk ----
+    for (int n = threadIdx.x; n < dstate; n += NT) carry_s[n] = 0.f;
+    __syncthreads();
+    for (int j = 0; j < nchunks; ++j) {
+        const int64_t t0 = (int64_t)j * CH + (int64_t)threadIdx.x * E;
+        float uu[E], dt[E];
+        load_row<E>(ur, t0, L, vec, uu);
+        load_row<E>(dr, t0, L, vec, dt);
+#pragma unroll
+        for (int e = 0; e < E; ++e) dt[e] = dt_of(dt[e]);
+        for (int n = 0; n < dstate; ++n) {
+            const float An = A[(int64_t)d * dstate + n];
+            float Bv[E], a[E], bb[E], h[E];
+            load_row<E>(Bm + (((int64_t)b * ngroups + g) * dstate + n) * L, t0, L, vec, Bv);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const bool ok = t0 + e < L;
+                a[e] = ok ? bem_fexp(dt[e] * An) : 1.f;
+                bb[e] = ok ? dt[e] * Bv[e] * uu[e] : 0.f;
+            }
+            float carry = carry_s[n];
+            if (threadIdx.x == 0) wsr[(int64_t)j * dstate + n] = carry;
+            block_scan_affine<NT, E, false>(a, bb, h, carry, agg);
+            if (threadIdx.x == 0) carry_s[n] = carry;
+        }
+        __syncthreads();
+    }
+    // ---- pass 2 ----
+    for (int n = threadIdx.x; n < dstate; n += NT) carry_s[n] = 0.f;     // dh entering from the right
+    __syncthreads();                                                      // also orders the ws stores of thread 0 before its re-reads
+    float accD = 0.f, accBias = 0.f;
+    for (int j = nchunks - 1; j >= 0; --j) {
+        const int64_t t0 = (int64_t)j * CH + (int64_t)threadIdx.x * E;
+        float uu[E], dl[E], dt[E], dy[E], duv[E], ddt[E];
+        load_row<E>(ur, t0, L, vec, uu);
+        load_row<E>(dr, t0, L, vec, dl);
+        load_row<E>(gr, t0, L, vec, dy);
+        const float dl_next = (t0 + E < L) ? dr[t0 + E] : 0.f;
+        const float dt_next = dt_of(dl_next);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            dt[e] = dt_of(dl[e]);
+            duv[e] = Dd * dy[e];
+            ddt[e] = 0.f;
+            accD += (t0 + e < L) ? dy[e] * uu[e] : 0.f;
+        }
+        for (int n = 0; n < dstate; ++n) {
+            const float An = A[(int64_t)d * dstate + n];
+            const int64_t bc = (((int64_t)b * ngroups + g) * dstate + n) * L;
+            float Bv[E], Cv[E], a[E], bb[E], h[E], ar[E], br[E], dh[E];
+            load_row<E>(Bm + bc, t0, L, vec, Bv);
+            load_row<E>(Cm + bc, t0, L, vec, Cv);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const bool ok = t0 + e < L;
+                a[e] = ok ? bem_fexp(dt[e] * An) : 1.f;
+                bb[e] = ok ? dt[e] * Bv[e] * uu[e] : 0.f;
+            }
+            float cf = wsr[(int64_t)j * dstate + n];
+            block_scan_affine<NT, E, false>(a, bb, h, cf, agg);
+            // reverse: dh_t = a_{t+1} dh_{t+1} + C_t dy_t
+            const float a_next = (t0 + E < L) ? bem_fexp(dt_next * An) : 1.f;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const bool ok = t0 + e < L;
+                ar[e] = (e + 1 < E) ? a[e + 1] : a_next;
+                if (!(t0 + e + 1 < L)) ar[e] = 1.f;
+                br[e] = ok ? Cv[e] * dy[e] : 0.f;
+            }
+            float cr = carry_s[n];
+            block_scan_affine<NT, E, true>(ar, br, dh, cr, agg);
+            if (threadIdx.x == 0) carry_s[n] = cr;
+            float accA = 0.f;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                if (t0 + e < L) {
+                    const float hm = h[e] - bb[e];                     // a_t * h_{t-1}
+                    duv[e] = fmaf(dh[e] * dt[e], Bv[e], duv[e]);
+                    ddt[e] += dh[e] * (Bv[e] * uu[e] + An * hm);
+                    accA = fmaf(dh[e] * dt[e], hm, accA);
+                    atomicAdd(dB + bc + t0 + e, dh[e] * dt[e] * uu[e]);
+                    atomicAdd(dC + bc + t0 + e, dy[e] * h[e]);
+                }
+            }
+            accA = block_reduce_sum<NT>(accA, red);
+            if (threadIdx.x == 0) atomicAdd(dA + (int64_t)d * dstate + n, accA);
+        }
+        float dd[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const float z = dl[e] + bias;
+            const float sg = (softplus && z <= 20.f) ? 1.f / (1.f + bem_fexp(-z)) : 1.f;
+            dd[e] = ddt[e] * sg;
+            accBias += (t0 + e < L) ? dd[e] : 0.f;
+        }
+        store_row<E>(du + row, t0, L, vec, duv);
+        store_row<E>(ddelta + row, t0, L, vec, dd);
+        __syncthreads();
+    }
+    accD = block_reduce_sum<NT>(accD, red);
+    accBias = block_reduce_sum<NT>(accBias, red);
+    if (threadIdx.x == 0) {
+        if (dD) atomicAdd(dD + d, accD);
+        if (ddbias) atomicAdd(ddbias + d, accBias);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Fused SS2D scan (N = 1): grid (C, B, 2 orientations).  Each workgroup owns one (b, c) sequence of
 // one orientation and runs its forward direction (k = o) and reverse direction (k = o + 2).
 // ------------------------------------------------------------------------------------------------
@@ -331,4 +491,33 @@ extern "C" int bem_cross_merge_f32(const float* ys, float* y, int B, int C, int 
     dim3 grid(cdiv(H * W, 256), C, B);
     cross_merge_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(ys, y, C, H, W);
     return bem_check_launch("cross_merge");
+}
+
+extern "C" int64_t bem_selective_scan_bwd_ws_elems(int batch, int dim, int L, int dstate) {
+    return (int64_t)batch * dim * cdiv(L > 0 ? L : 1, 1024) * dstate;
+}
+
+extern "C" int bem_selective_scan_bwd_f32(const float* u, const float* delta, const float* A, const float* Bm,
+                                          const float* Cm, const float* D, const float* delta_bias, const float* dout,
+                                          float* ws, float* du, float* ddelta, float* dA, float* dB, float* dC, float* dD,
+                                          float* ddelta_bias, int batch, int dim, int L, int dstate, int ngroups,
+                                          int delta_softplus, void* stream) {
+    BEM_REQUIRE(u && delta && A && Bm && Cm && dout && ws && du && ddelta && dA && dB && dC, "selective_scan_bwd: null tensor");
+    BEM_REQUIRE((D == nullptr) == (dD == nullptr) && (delta_bias == nullptr) == (ddelta_bias == nullptr),
+                "selective_scan_bwd: dD / ddelta_bias must be given exactly when D / delta_bias are");
+    BEM_REQUIRE(batch >= 0 && batch <= 65535 && dim > 0 && L >= 0, "selective_scan_bwd: bad shape");
+    BEM_REQUIRE(dstate >= 1 && dstate <= 256 && ngroups >= 1 && dim % ngroups == 0, "selective_scan_bwd: dstate / groups");
+    if (batch == 0 || L == 0) return BEM_OK;
+    hipStream_t s = (hipStream_t)stream;
+    // accumulated outputs start from zero (the reference allocates them with zeros_like, selective_scan_oflex.cpp:318-332)
+    bool ok = hipMemsetAsync(dA, 0, sizeof(float) * (size_t)dim * dstate, s) == hipSuccess;
+    ok = ok && hipMemsetAsync(dB, 0, sizeof(float) * (size_t)batch * ngroups * dstate * L, s) == hipSuccess;
+    ok = ok && hipMemsetAsync(dC, 0, sizeof(float) * (size_t)batch * ngroups * dstate * L, s) == hipSuccess;
+    if (dD) ok = ok && hipMemsetAsync(dD, 0, sizeof(float) * (size_t)dim, s) == hipSuccess;
+    if (ddelta_bias) ok = ok && hipMemsetAsync(ddelta_bias, 0, sizeof(float) * (size_t)dim, s) == hipSuccess;
+    if (!ok) return bem_check_launch("selective_scan_bwd memset");
+    dim3 grid(dim, batch);
+    selective_scan_bwd_kernel<256, 4><<<grid, 256, 0, s>>>(u, delta, A, Bm, Cm, D, delta_bias, dout, ws, du, ddelta, dA, dB, dC, dD,
+                                                           ddelta_bias, dim, L, dstate, ngroups, delta_softplus);
+    return bem_check_launch("selective_scan_bwd");
 }

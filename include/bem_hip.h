@@ -42,6 +42,18 @@ int bem_selective_scan_fwd_f32(const float* u, const float* delta, const float* 
                                int batch, int dim, int L, int dstate, int ngroups, int delta_softplus,
                                void* stream);
 
+/* Replaces selective_scan_cuda_oflex.bwd (selective_scan_oflex.cpp:245-358, kernel selective_scan_bwd_kernel_oflex.cuh:73-289),
+ * f32.  dout, du, ddelta: (batch, dim, L); dA (dim, dstate); dB, dC (batch, ngroups, dstate, L) f32; dD, ddelta_bias (dim)
+ * or NULL exactly when D / delta_bias are NULL.  ws: scratch of bem_selective_scan_bwd_ws_elems(...) floats (the role of
+ * the reference's opaque `x` blob; recomputed here, so the forward need not be re-run by the caller).  dA/dB/dC/dD/
+ * ddelta_bias are zeroed by the call and accumulated with float atomics across batch / group members (run-to-run
+ * last-bit differences, like the reference). */
+int64_t bem_selective_scan_bwd_ws_elems(int batch, int dim, int L, int dstate);
+int bem_selective_scan_bwd_f32(const float* u, const float* delta, const float* A, const float* Bm, const float* Cm,
+                               const float* D, const float* delta_bias, const float* dout, float* ws, float* du,
+                               float* ddelta, float* dA, float* dB, float* dC, float* dD, float* ddelta_bias,
+                               int batch, int dim, int L, int dstate, int ngroups, int delta_softplus, void* stream);
+
 /* Replaces cross_scan_fn / triton_cross_scan_flex (csm_triton.py:278-423): x (B,C,H,W) -> xs (B,4,C,H*W). */
 int bem_cross_scan_f32(const float* x, float* xs, int B, int C, int H, int W, void* stream);
 /* Replaces cross_merge_fn (csm_triton.py:446-471): ys (B,4,C,H,W) -> y (B,C,H*W). */
