@@ -5,7 +5,8 @@ from basicsr.utils import get_root_logger
 from basicsr.utils.registry import ARCH_REGISTRY
 from bem import archs as _a
 
-for _cls in (_a.Network, _a.DecompDualBranchDDWavelet, _a.DecompSingleBranch):
+for _cls in (_a.Network, _a.DecompDualBranchDDWavelet, _a.DecompSingleBranch, _a.DecompDualBranch2DD, _a.DecompDualBranch2,
+             _a.DecompSingleBranchDD):
     if _cls.__name__ not in ARCH_REGISTRY:
         ARCH_REGISTRY.register(_cls)
 

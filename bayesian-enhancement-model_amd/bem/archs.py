@@ -254,6 +254,124 @@ def _bcast_copy(d_img, i, q, spi, src_c0):
 
 
 # ------------------------------------------------------------------------------------------------
+# Sibling Stage-II archs: same blocks and kernels, different wiring of the condition
+# ------------------------------------------------------------------------------------------------
+class _DualBranchFullRes(nn.Module):
+    """Shared body of DecompDualBranch2DD / DecompDualBranch2: two full-resolution U-Nets over quaternion maps,
+    shared bottleneck, Hamilton product of the two 4-channel outputs (no wavelet stage)."""
+
+    def _build(self, in_branch, n_feat, num_blocks, d_state, ssm_ratio, mlp_ratio, mlp_type, last_act, decomp_model):
+        self.num_levels = len(num_blocks)
+        if isinstance(d_state, int):
+            d_state = [d_state] * self.num_levels
+        if decomp_model not in ("model1", "model2", "model3", "model4"):
+            raise ValueError(f"Unknown decomp_model: {decomp_model}")
+        self.decomp = Decomp.from_shipped(decomp_model, wavelet_out=False)
+        for br in ("Q1", "Q2"):
+            fc = Conv2dK(in_branch, n_feat, 3, 1, 1, bias=True)
+            nn.init.kaiming_normal_(fc.weight, mode="fan_out", nonlinearity="linear")
+            nn.init.zeros_(fc.bias)
+            setattr(self, f"first_conv_{br}", fc)
+            enc, cur = nn.ModuleList(), n_feat
+            for i in range(self.num_levels - 1):
+                enc.append(make_vss_level(cur, num_blocks[i], d_state[i], ssm_ratio, mlp_ratio, mlp_type))
+                cur *= 2
+            setattr(self, f"encoders_{br}", enc)
+            setattr(self, f"down_layers_{br}", nn.ModuleList([conv_down(n_feat * (2 ** i)) for i in range(self.num_levels - 1)]))
+        self.bottleneck_fuse = PwConv2d(cur * 2, cur, bias=False)
+        self.bottleneck_block = make_vss_level(cur, num_blocks[-1], d_state[-1], ssm_ratio, mlp_ratio, mlp_type)
+        self.bottleneck_to_Q1 = PwConv2d(cur, cur, bias=False)
+        self.bottleneck_to_Q2 = PwConv2d(cur, cur, bias=False)
+        for br in ("Q1", "Q2"):
+            d, decs = cur, nn.ModuleList()
+            for i in range(self.num_levels - 2, -1, -1):
+                decs.append(_decoder(d, num_blocks[i], d_state[i], ssm_ratio, mlp_ratio, mlp_type))
+                d //= 2
+            setattr(self, f"decoders_{br}", decs)
+            pj = Conv2dK(n_feat, 4, 3, 1, 1, bias=True)
+            nn.init.zeros_(pj.bias)
+            setattr(self, f"proj_{br}", pj)
+        self.last_act = _check_last_act(last_act)
+        self.apply(_init_weights)
+
+    def _dual_unet(self, q1, q2):
+        """q1, q2 (B,Cin,H,W) -> Hamilton(Q1_out, Q2_out)[1:]  (B,3,H,W)."""
+        feats, skips = {}, {}
+        for br, q in (("Q1", q1), ("Q2", q2)):
+            f = getattr(self, f"first_conv_{br}")(q)
+            sk = []
+            for i in range(self.num_levels - 1):
+                f = getattr(self, f"encoders_{br}")[i](f)
+                sk.append(f)
+                f = getattr(self, f"down_layers_{br}")[i](f)
+            feats[br], skips[br] = f, sk
+        fused = self.bottleneck_block(self.bottleneck_fuse(feats["Q1"], x2=feats["Q2"], in_mode=2))
+        B, _, H, W = q1.shape
+        out8 = torch.empty(B, 8, H, W, device=q1.device, dtype=q1.dtype)
+        for bi, br in enumerate(("Q1", "Q2")):
+            f = getattr(self, f"bottleneck_to_{br}")(fused)
+            for j, dec in enumerate(getattr(self, f"decoders_{br}")):
+                f = dec["up"](f)
+                f = dec["fuse"](f, x2=skips[br][self.num_levels - 2 - j], in_mode=2)
+                f = dec["block"](f)
+            ops.copy_channels(getattr(self, f"proj_{br}")(f), out8, 4 * bi)
+        return ops.hamilton(out8)
+
+
+class DecompDualBranch2DD(_DualBranchFullRes):
+    """basicsr/archs/DecompDualBranchDD_arch.py:53-302: Q = cat(Q_img, Q_cond) (8 channels per branch)."""
+
+    def __init__(self, in_channels=3, out_channels=3, n_feat=40, stage=1, num_blocks=[2, 2, 2], d_state=1, ssm_ratio=1,
+                 mlp_ratio=4, mlp_type="gdmlp", use_pixelshuffle=False, drop_path=0.0, use_illu=False, sam=False,
+                 last_act=None, decomp_model="model1"):
+        super().__init__()
+        self.stage = stage
+        self._build(8, n_feat, num_blocks, d_state, ssm_ratio, mlp_ratio, mlp_type, last_act, decomp_model)
+
+    def forward(self, x, mask=None):
+        _need_cuda(x)
+        with torch.no_grad():
+            x = x.contiguous()
+            B, _, H, W = x.shape
+            qi, qc = self.decomp(x, 0), self.decomp(x, 3)              # each (B,8,H,W) = [Q1 | Q2]
+            qs = []
+            for bi in range(2):
+                q = torch.empty(B, 8, H, W, device=x.device, dtype=x.dtype)
+                ops.copy_channels(qi, q, 0, src_c0=4 * bi, C=4)
+                ops.copy_channels(qc, q, 4, src_c0=4 * bi, C=4)
+                qs.append(q)
+            out = self._dual_unet(qs[0], qs[1])
+        return [x, out]
+
+
+class DecompDualBranch2(_DualBranchFullRes):
+    """basicsr/archs/DecompDualBranch_arch.py:51-298: Q = Q_img + [cond, 0] (4 channels per branch); returns
+    [x[:, 0:3], out] like the reference."""
+
+    def __init__(self, in_channels=3, out_channels=3, n_feat=40, stage=1, num_blocks=[2, 2, 2], d_state=1, ssm_ratio=1,
+                 mlp_ratio=4, mlp_type="gdmlp", use_pixelshuffle=False, drop_path=0.0, use_illu=False, sam=False,
+                 last_act=None, decomp_model="model1"):
+        super().__init__()
+        self.stage = stage
+        self._build(4, n_feat, num_blocks, d_state, ssm_ratio, mlp_ratio, mlp_type, last_act, decomp_model)
+
+    def forward(self, x, mask=None):
+        _need_cuda(x)
+        with torch.no_grad():
+            x = x.contiguous()
+            B, _, H, W = x.shape
+            qi = self.decomp(x, 0)
+            qs = []
+            for bi in range(2):
+                q = torch.empty(B, 4, H, W, device=x.device, dtype=x.dtype)
+                ops.copy_channels(qi, q, 0, src_c0=4 * bi, C=4)
+                ops.add_channels(x, q, 0, src_c0=3, C=3)               # + [cond, 0]
+                qs.append(q)
+            out = self._dual_unet(qs[0], qs[1])
+        return [x[:, 0:3], out]
+
+
+# ------------------------------------------------------------------------------------------------
 # Stage-II: DecompSingleBranch (BASELINE config 1)
 # ------------------------------------------------------------------------------------------------
 class DecompSingleBranch(nn.Module):
@@ -298,18 +416,47 @@ class DecompSingleBranch(nn.Module):
             fea = torch.empty(B, 11, H, W, device=x.device, dtype=x.dtype)
             ops.copy_channels(q, fea, 0)
             ops.copy_channels(x, fea, 8, src_c0=3, C=3)
-            f = self.first_conv(fea)
-            sk = []
-            for i in range(self.num_levels - 1):
-                f = self.encoders[i](f)
-                sk.append(f)
-                f = self.down_layers[i](f)
-            f = self.bottleneck(f)
-            for j, dec in enumerate(self.decoders):
-                f = dec["up"](f)
-                f = dec["fuse"](f, x2=sk[self.num_levels - 2 - j], in_mode=2)
-                f = dec["block"](f)
-            out = ops.hamilton(self.proj(f))
+            out = ops.hamilton(self._unet(fea))
+        return [x, out]
+
+    def _unet(self, fea):
+        f = self.first_conv(fea)
+        sk = []
+        for i in range(self.num_levels - 1):
+            f = self.encoders[i](f)
+            sk.append(f)
+            f = self.down_layers[i](f)
+        f = self.bottleneck(f)
+        for j, dec in enumerate(self.decoders):
+            f = dec["up"](f)
+            f = dec["fuse"](f, x2=sk[self.num_levels - 2 - j], in_mode=2)
+            f = dec["block"](f)
+        return self.proj(f)
+
+
+class DecompSingleBranchDD(DecompSingleBranch):
+    """basicsr/archs/DecompSingleBranchDD_arch.py:53-251: the condition is decomposed too; the single U-Net sees
+    cat(Q1_img, Q2_img, Q1_cond, Q2_cond) (16 channels)."""
+
+    def __init__(self, in_channels=6, out_channels=3, n_feat=40, stage=1, num_blocks=[2, 2, 2], d_state=1, ssm_ratio=1,
+                 mlp_ratio=4, mlp_type="gdmlp", use_pixelshuffle=False, drop_path=0.0, use_illu=False, sam=False,
+                 last_act=None, decomp_model="model1"):
+        super().__init__(in_channels, out_channels, n_feat, stage, num_blocks, d_state, ssm_ratio, mlp_ratio, mlp_type,
+                         use_pixelshuffle, drop_path, use_illu, sam, last_act, decomp_model)
+        del self.conditioning_channels
+        self.first_conv = Conv2dK(16, n_feat, 3, 1, 1, bias=True)
+        nn.init.kaiming_normal_(self.first_conv.weight, mode="fan_out", nonlinearity="linear")
+        nn.init.zeros_(self.first_conv.bias)
+
+    def forward(self, x, mask=None):
+        _need_cuda(x)
+        with torch.no_grad():
+            x = x.contiguous()
+            B, _, H, W = x.shape
+            fea = torch.empty(B, 16, H, W, device=x.device, dtype=x.dtype)
+            ops.copy_channels(self.decomp(x, 0), fea, 0)
+            ops.copy_channels(self.decomp(x, 3), fea, 8)
+            out = ops.hamilton(self._unet(fea))
         return [x, out]
 
 

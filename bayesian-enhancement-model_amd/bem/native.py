@@ -70,13 +70,14 @@ SIGNATURES = {
     "bem_attn_fold_f32": [P, P, P, P, P, P, I, I, P],
     "bem_transpose_planes_f32": [P, I64, P, I64, I, I, I, I, P],
     "bem_copy_channels_f32": [P, I64, P, I64, I, I, I, P],
+    "bem_add_channels_f32": [P, I64, P, I64, I, I, I, P],
     "bem_bilinear_up_f32": [P, I64, P, I64, I, I, I, I, I, P],
     "bem_space_to_depth_f32": [P, P, I, I, I, I, P],
     "bem_pixel_shuffle2_f32": [P, P, I, I, I, I, P],
     "bem_bnn_sample_f32": [P, P, P, P, I, I64, U64, U64, P],
     "bem_cond_postproc_f32": [P, P, P, P, I, I, I, I, F, P],
     "bem_plane_mean_f32": [P, P, I, I, I, I, I, P],
-    "bem_candidate_finalize_f32": [P, P, P, P, I, I, I, I, I, I, I, P],
+    "bem_candidate_finalize_f32": [P, P, P, P, P, I, I, I, I, I, I, I, P],
     "bem_last_error": [],
     "bem_abi_version": [],
 }

@@ -412,6 +412,20 @@ def copy_channels(src, dst, dst_c0, src_c0=0, C=None):
     return dst
 
 
+def add_channels(src, dst, dst_c0, src_c0=0, C=None):
+    """dst[:, dst_c0:dst_c0+C] += src[:, src_c0:src_c0+C] (same spatial size)."""
+    _chk(src, "src"); _chk(dst, "dst")
+    B, Cs = src.shape[0], src.shape[1]
+    C = Cs - src_c0 if C is None else C
+    L = src[0, 0].numel()
+    if dst.shape[0] != B or dst[0, 0].numel() != L or dst_c0 + C > dst.shape[1] or src_c0 + C > Cs:
+        raise ValueError("add_channels: shapes")
+    check(lib().bem_add_channels_f32(ctypes.c_void_p(src.data_ptr() + 4 * src_c0 * L), Cs * L,
+                                     ctypes.c_void_p(dst.data_ptr() + 4 * dst_c0 * L), dst.shape[1] * L, B, C, L,
+                                     _stream()), "add_channels")
+    return dst
+
+
 def bilinear_up(src, s, dst=None, dst_c0=0):
     _chk(src, "src")
     B, C, H, W = src.shape
@@ -494,7 +508,8 @@ def candidate_finalize(pred, target, samples_per_image, h, w, gt_mean):
         raise ValueError("candidate_finalize: target shape")
     fin = torch.empty(Bn, 3, h, w, device=pred.device, dtype=pred.dtype)
     ps = torch.zeros(Bn, device=pred.device, dtype=pred.dtype)
-    check(lib().bem_candidate_finalize_f32(_p(pred), _p(target), _p(fin), _p(ps), Bn, samples_per_image, Hp, Wp, h, w,
+    ws = torch.empty(7 * Bn, device=pred.device, dtype=torch.float64)
+    check(lib().bem_candidate_finalize_f32(_p(pred), _p(target), _p(fin), _p(ps), _p(ws), Bn, samples_per_image, Hp, Wp, h, w,
                                            int(bool(gt_mean)), _stream()), "candidate_finalize")
     return fin, ps
 

@@ -302,11 +302,14 @@ __global__ __launch_bounds__(256) void transpose_planes_kernel(const float* __re
     float* d = dst + (int64_t)bq * dst_bs + (int64_t)pq * HW;
     const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    float v[4];
 #pragma unroll
-    for (int k = 0; k < 32; k += 8) {
-        const int y = y0 + ty + k, x = x0 + tx;
-        if (y < H && x < W) t[ty + k][tx] = s[(int64_t)y * W + x];
+    for (int k = 0; k < 4; ++k) {                   // clamped addresses: four loads in flight, then the LDS stores
+        const int y = min(y0 + ty + 8 * k, H - 1), x = min(x0 + tx, W - 1);
+        v[k] = s[(int64_t)y * W + x];
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[ty + 8 * k][tx] = v[k];
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 32; k += 8) {
@@ -321,6 +324,14 @@ __global__ void copy_channels_kernel(const float* __restrict__ src, int64_t src_
     if (i >= total) return;
     const int64_t b = i / CL, r = i - b * CL;
     dst[b * dst_bs + r] = src[b * src_bs + r];
+}
+
+__global__ void add_channels_kernel(const float* __restrict__ src, int64_t src_bs, float* __restrict__ dst,
+                                    int64_t dst_bs, int64_t CL, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t b = i / CL, r = i - b * CL;
+    dst[b * dst_bs + r] += src[b * src_bs + r];
 }
 
 __global__ void bilinear_up_kernel(const float* __restrict__ src, int64_t src_bs, float* __restrict__ dst,
@@ -447,44 +458,65 @@ __global__ __launch_bounds__(256) void cond_postproc_kernel(const float* __restr
     }
 }
 
-__global__ __launch_bounds__(256) void candidate_finalize_kernel(const float* __restrict__ pred,
-                                                                 const float* __restrict__ target,
-                                                                 float* __restrict__ fin, float* __restrict__ psnr,
-                                                                 int spi, int Hp, int Wp, int h, int w, int gt_mean) {
-    // one workgroup per candidate
+// Candidate finalisation in three small grids (one workgroup per candidate left 250 of 256 CUs idle):
+//   sums   : per (candidate, channel) sum of the clamped crop and of the target      -> ws[bn][ch][0..1]  (f64 atomics)
+//   final  : GT-mean ratio from those sums, clipped candidate out, squared error     -> ws[bn][6]
+//   psnr   : 10 log10(1 / mse)
+constexpr int CF_CHUNK = 4096;
+__global__ __launch_bounds__(256) void cand_sums_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                        double* __restrict__ ws, int spi, int Hp, int Wp, int h, int w) {
     __shared__ double sh[4];
-    const int bn = blockIdx.x;
+    const int plane = blockIdx.y, bn = plane / 3, ch = plane - bn * 3;
     const int64_t hw = (int64_t)h * w;
-    const float* tg = target ? target + (int64_t)(bn / spi) * 3 * hw : nullptr;
+    const float* p = pred + (int64_t)plane * Hp * Wp;
+    const float* tg = target + ((int64_t)(bn / spi) * 3 + ch) * hw;
+    double sp = 0, st = 0;
+    const int i0 = blockIdx.x * CF_CHUNK;
+    for (int i = i0 + threadIdx.x; i < i0 + CF_CHUNK && i < hw; i += 256) {
+        sp += (double)fminf(fmaxf(p[(int64_t)(i / w) * Wp + (i % w)], 0.f), 1.f);
+        st += (double)tg[i];
+    }
+    sp = block_sum(sp, sh);
+    st = block_sum(st, sh);
+    if (threadIdx.x == 0) {
+        atomicAdd(&ws[(int64_t)bn * 7 + ch * 2], sp);
+        atomicAdd(&ws[(int64_t)bn * 7 + ch * 2 + 1], st);
+    }
+}
+
+__global__ __launch_bounds__(256) void cand_final_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                         float* __restrict__ fin, double* __restrict__ ws, int spi, int Hp,
+                                                         int Wp, int h, int w, int gt_mean) {
+    __shared__ double sh[4];
+    const int plane = blockIdx.y, bn = plane / 3, ch = plane - bn * 3;
+    const int64_t hw = (int64_t)h * w;
+    const float* p = pred + (int64_t)plane * Hp * Wp;
+    const float* tg = target ? target + ((int64_t)(bn / spi) * 3 + ch) * hw : nullptr;
+    float ratio = 1.f;
+    if (gt_mean) {
+        const double sp = ws[(int64_t)bn * 7 + ch * 2], st = ws[(int64_t)bn * 7 + ch * 2 + 1];
+        ratio = (float)(st / (double)hw) / (float)(sp / (double)hw);
+    }
     double mse = 0;
-    for (int ch = 0; ch < 3; ++ch) {
-        const float* p = pred + ((int64_t)bn * 3 + ch) * Hp * Wp;
-        float ratio = 1.f;
-        if (gt_mean) {
-            double sp = 0, st = 0;
-            for (int i = threadIdx.x; i < hw; i += 256) {
-                sp += (double)fminf(fmaxf(p[(int64_t)(i / w) * Wp + (i % w)], 0.f), 1.f);
-                st += (double)tg[(int64_t)ch * hw + i];
-            }
-            sp = block_sum(sp, sh);
-            st = block_sum(st, sh);
-            ratio = (float)(st / (double)hw) / (float)(sp / (double)hw);
-        }
-        for (int i = threadIdx.x; i < hw; i += 256) {
-            float v = fminf(fmaxf(p[(int64_t)(i / w) * Wp + (i % w)], 0.f), 1.f);
-            if (gt_mean) v = fminf(fmaxf(v * ratio, 0.f), 1.f);
-            fin[((int64_t)bn * 3 + ch) * hw + i] = v;
-            if (tg) {
-                const double d = (double)tg[(int64_t)ch * hw + i] - (double)v;
-                mse += d * d;
-            }
+    const int i0 = blockIdx.x * CF_CHUNK;
+    for (int i = i0 + threadIdx.x; i < i0 + CF_CHUNK && i < hw; i += 256) {
+        float v = fminf(fmaxf(p[(int64_t)(i / w) * Wp + (i % w)], 0.f), 1.f);
+        if (gt_mean) v = fminf(fmaxf(v * ratio, 0.f), 1.f);
+        fin[(int64_t)plane * hw + i] = v;
+        if (tg) {
+            const double d = (double)tg[i] - (double)v;
+            mse += d * d;
         }
     }
     mse = block_sum(mse, sh);
-    if (threadIdx.x == 0 && psnr) {
-        const double m = mse / (3.0 * (double)hw);
-        psnr[bn] = tg ? (m == 0 ? 100.f : (float)(10.0 * log10(1.0 / m))) : 0.f;
-    }
+    if (threadIdx.x == 0 && tg) atomicAdd(&ws[(int64_t)bn * 7 + 6], mse);
+}
+
+__global__ void cand_psnr_kernel(const double* __restrict__ ws, float* __restrict__ psnr, int Bn, int64_t hw, int has_target) {
+    const int bn = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bn >= Bn) return;
+    const double m = ws[(int64_t)bn * 7 + 6] / (3.0 * (double)hw);
+    psnr[bn] = has_target ? (m == 0 ? 100.f : (float)(10.0 * log10(1.0 / m))) : 0.f;
 }
 
 }  // namespace
@@ -577,6 +609,16 @@ extern "C" int bem_copy_channels_f32(const float* src, int64_t src_bstride, floa
     return bem_check_launch("copy_channels");
 }
 
+extern "C" int bem_add_channels_f32(const float* src, int64_t src_bstride, float* dst, int64_t dst_bstride, int B,
+                                    int C, int L, void* stream) {
+    BEM_REQUIRE(src && dst, "add_channels: null tensor");
+    BEM_REQUIRE(B >= 0 && C > 0 && L >= 0, "add_channels: bad shape");
+    const int64_t total = (int64_t)B * C * L;
+    if (total == 0) return BEM_OK;
+    add_channels_kernel<<<GRID1D(total), 256, 0, (hipStream_t)stream>>>(src, src_bstride, dst, dst_bstride, (int64_t)C * L, total);
+    return bem_check_launch("add_channels");
+}
+
 extern "C" int bem_bilinear_up_f32(const float* src, int64_t src_bstride, float* dst, int64_t dst_bstride, int B, int C,
                                    int H, int W, int s, void* stream) {
     BEM_REQUIRE(src && dst, "bilinear_up: null tensor");
@@ -633,12 +675,17 @@ extern "C" int bem_plane_mean_f32(const float* x, float* means, int P, int Hs, i
 }
 
 extern "C" int bem_candidate_finalize_f32(const float* pred, const float* target, float* final_out, float* psnr,
-                                          int Bn, int samples_per_image, int Hp, int Wp, int h, int w, int gt_mean,
+                                          double* ws, int Bn, int samples_per_image, int Hp, int Wp, int h, int w, int gt_mean,
                                           void* stream) {
-    BEM_REQUIRE(pred && final_out, "candidate_finalize: null tensor");
-    BEM_REQUIRE(Bn >= 0 && samples_per_image >= 1 && h > 0 && w > 0 && h <= Hp && w <= Wp, "candidate_finalize: bad shape");
+    BEM_REQUIRE(pred && final_out && ws, "candidate_finalize: null tensor");
+    BEM_REQUIRE(Bn >= 0 && 3 * (int64_t)Bn <= 65535 && samples_per_image >= 1 && h > 0 && w > 0 && h <= Hp && w <= Wp, "candidate_finalize: bad shape");
     BEM_REQUIRE(!gt_mean || target, "candidate_finalize: GT_mean needs a target");
     if (Bn == 0) return BEM_OK;
-    candidate_finalize_kernel<<<Bn, 256, 0, (hipStream_t)stream>>>(pred, target, final_out, psnr, samples_per_image, Hp, Wp, h, w, gt_mean);
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(ws, 0, sizeof(double) * 7 * (size_t)Bn, s) != hipSuccess) return bem_check_launch("candidate_finalize memset");
+    dim3 grid(cdiv(h * w, CF_CHUNK), 3 * Bn);
+    if (gt_mean) cand_sums_kernel<<<grid, 256, 0, s>>>(pred, target, ws, samples_per_image, Hp, Wp, h, w);
+    cand_final_kernel<<<grid, 256, 0, s>>>(pred, target, final_out, ws, samples_per_image, Hp, Wp, h, w, gt_mean);
+    if (psnr) cand_psnr_kernel<<<cdiv(Bn, 256), 256, 0, s>>>(ws, psnr, Bn, (int64_t)h * w, target != nullptr);
     return bem_check_launch("candidate_finalize");
 }

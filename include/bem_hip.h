@@ -181,6 +181,9 @@ int bem_transpose_planes_f32(const float* src, int64_t src_bstride, float* dst, 
 /* dst[b][dst_c0 + c][l] = src[b][c][l]  (c < C), strides in elements. */
 int bem_copy_channels_f32(const float* src, int64_t src_bstride, float* dst, int64_t dst_bstride,
                           int B, int C, int L, void* stream);
+/* dst[b][c][l] += src[b][c][l]  (c < C); DecompDualBranch2's "Q + [cond, 0]" (DecompDualBranch_arch.py:241-246). */
+int bem_add_channels_f32(const float* src, int64_t src_bstride, float* dst, int64_t dst_bstride,
+                         int B, int C, int L, void* stream);
 /* F.interpolate(scale_factor=s, mode='bilinear', align_corners=False) (eval.py:220, UNet_arch.py:130). */
 int bem_bilinear_up_f32(const float* src, int64_t src_bstride, float* dst, int64_t dst_bstride,
                         int B, int C, int H, int W, int s, void* stream);
@@ -206,9 +209,9 @@ int bem_plane_mean_f32(const float* x, float* means, int P, int Hs, int Ws, int 
 /* Candidate finalisation (eval.py:222-226,246-252, Enhancement/utils.py:5-9): crop to (h,w), clamp to
  * [0,1], optional per-channel GT-mean rescale + clip, write final (Bn,3,h,w) and PSNR (Bn) vs target
  * (n_img,3,h,w).  pred is (Bn,3,Hp,Wp). */
-int bem_candidate_finalize_f32(const float* pred, const float* target, float* final_out, float* psnr,
+int bem_candidate_finalize_f32(const float* pred, const float* target, float* final_out, float* psnr, double* ws,
                                int Bn, int samples_per_image, int Hp, int Wp, int h, int w, int gt_mean,
-                               void* stream);
+                               void* stream);   /* ws: scratch of 7*Bn doubles (zeroed by the call) */
 
 #ifdef __cplusplus
 }

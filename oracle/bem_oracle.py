@@ -372,6 +372,69 @@ def singlebranch_ref(sd: SD, x, scan=selective_scan_ref, pre: str = ""):
     return hamilton_ref(out[:, :4], out[:, 4:])[:, 1:]
 
 
+def _dual_unet_ref(sd: SD, pre: str, q1, q2, scan):
+    """Two-branch U-Net body shared by the dual-branch archs (…DD_arch.py:253-296): returns (Q1_out, Q2_out)."""
+    nl = _levels(sd, pre + "down_layers_Q1.") + 1
+    feats, skips = {}, {}
+    for br, q in (("Q1", q1), ("Q2", q2)):
+        f = F.conv2d(q, sd[f"{pre}first_conv_{br}.weight"], sd[f"{pre}first_conv_{br}.bias"], padding=1)
+        sk = []
+        for i in range(nl - 1):
+            f = _blocks(sd, f"{pre}encoders_{br}.{i}.", f, None, scan)
+            sk.append(f)
+            f = F.conv2d(f, sd[f"{pre}down_layers_{br}.{i}.weight"], None, stride=2, padding=1)
+        feats[br], skips[br] = f, sk
+    fused = F.conv2d(torch.cat([feats["Q1"], feats["Q2"]], 1), sd[pre + "bottleneck_fuse.weight"])
+    fused = _blocks(sd, pre + "bottleneck_block.", fused, None, scan)
+    outs = []
+    for br in ("Q1", "Q2"):
+        f = F.conv2d(fused, sd[f"{pre}bottleneck_to_{br}.weight"])
+        for j in range(nl - 1):
+            d = f"{pre}decoders_{br}.{j}."
+            f = F.conv_transpose2d(f, sd[d + "up.weight"], sd[d + "up.bias"], stride=2)
+            f = F.conv2d(torch.cat([f, skips[br][nl - 2 - j]], 1), sd[d + "fuse.weight"])
+            f = _blocks(sd, d + "block.", f, None, scan)
+        outs.append(F.conv2d(f, sd[f"{pre}proj_{br}.weight"], sd[f"{pre}proj_{br}.bias"], padding=1))
+    return outs
+
+
+def dualbranch2dd_ref(sd: SD, x, scan=selective_scan_ref, pre: str = ""):
+    """DecompDualBranch2DD.forward (DecompDualBranchDD_arch.py:239-299)."""
+    q1i, q2i = decomp_full_ref(sd, pre + "decomp.", x[:, 0:3])
+    q1c, q2c = decomp_full_ref(sd, pre + "decomp.", x[:, 3:6])
+    o1, o2 = _dual_unet_ref(sd, pre, torch.cat([q1i, q1c], 1), torch.cat([q2i, q2c], 1), scan)
+    return hamilton_ref(o1, o2)[:, 1:]
+
+
+def dualbranch2_ref(sd: SD, x, scan=selective_scan_ref, pre: str = ""):
+    """DecompDualBranch2.forward (DecompDualBranch_arch.py:231-298): Q = Q_img + [cond, 0]."""
+    q1i, q2i = decomp_full_ref(sd, pre + "decomp.", x[:, 0:3])
+    cq = torch.cat([x[:, 3:6], torch.zeros_like(x[:, 0:1])], 1)
+    o1, o2 = _dual_unet_ref(sd, pre, q1i + cq, q2i + cq, scan)
+    return hamilton_ref(o1, o2)[:, 1:]
+
+
+def singlebranchdd_ref(sd: SD, x, scan=selective_scan_ref, pre: str = ""):
+    """DecompSingleBranchDD.forward (DecompSingleBranchDD_arch.py:205-250)."""
+    q1i, q2i = decomp_full_ref(sd, pre + "decomp.", x[:, 0:3])
+    q1c, q2c = decomp_full_ref(sd, pre + "decomp.", x[:, 3:6])
+    f = F.conv2d(torch.cat([q1i, q2i, q1c, q2c], 1), sd[pre + "first_conv.weight"], sd[pre + "first_conv.bias"], padding=1)
+    nl = _levels(sd, pre + "down_layers.") + 1
+    sk = []
+    for i in range(nl - 1):
+        f = _blocks(sd, f"{pre}encoders.{i}.", f, None, scan)
+        sk.append(f)
+        f = F.conv2d(f, sd[f"{pre}down_layers.{i}.weight"], None, stride=2, padding=1)
+    f = _blocks(sd, pre + "bottleneck.", f, None, scan)
+    for j in range(nl - 1):
+        d = f"{pre}decoders.{j}."
+        f = F.conv_transpose2d(f, sd[d + "up.weight"], sd[d + "up.bias"], stride=2)
+        f = F.conv2d(torch.cat([f, sk[nl - 2 - j]], 1), sd[d + "fuse.weight"])
+        f = _blocks(sd, d + "block.", f, None, scan)
+    out = F.conv2d(f, sd[pre + "proj.weight"], sd[pre + "proj.bias"], padding=1)
+    return hamilton_ref(out[:, :4], out[:, 4:])[:, 1:]
+
+
 # ----------------------------------------------------------------------------------------------
 # A1/A2  Stage-I Bayesian U-Net     basicsr/archs/UNet_arch.py:58-82,97-155,245-361,364-474
 # ----------------------------------------------------------------------------------------------

@@ -173,6 +173,31 @@ def main():
         save(f"g6_{tag}", sd=sd, x=x6, gt=gt, out=out, loss=loss, grad_norm=gnorm, grads={k: gd[k] for k in picks},
              keys=np.array(list(net.state_dict().keys())))
 
+    # ---- G9 sibling Stage-II archs, reduced width, 1x6x32x32 --------------------
+    print("G9 sibling archs")
+    kw9 = {**kw, "n_feat": 8, "num_blocks": [1, 1, 1]}
+    lq9, gt9 = synth((1, 3, 32, 32), 287128)
+    x9 = torch.cat([lq9, (gt9 + 0.1 * torch.randn(1, 3, 32, 32, generator=torch.Generator().manual_seed(9))).clamp(0, 1)], 1)
+    contract9 = {}
+    for tag, ctor, dm in (("dualdd", ns.dd.DecompDualBranch2DD, "model4"), ("dual2", ns.dual2.DecompDualBranch2, "model1"),
+                          ("singledd", ns.singledd.DecompSingleBranchDD, "model1")):
+        torch.manual_seed(100)
+        with rh.ref_ctor_env():
+            net = ctor(decomp_model=dm, **kw9)
+            full = ctor(decomp_model=dm, **{**kw, "n_feat": 40, "num_blocks": [2, 2, 2]})
+        gg = torch.Generator().manual_seed(7)
+        with torch.no_grad():
+            for n, p_ in net.named_parameters():
+                if not n.startswith("decomp.") and ("norm" in n or n.endswith("bias")):
+                    p_.add_(0.05 * torch.randn(p_.shape, generator=gg))
+        net.eval()
+        with torch.no_grad():
+            res = net(x9)
+        sd = {k: v for k, v in net.state_dict().items() if not k.startswith("decomp.")}
+        save(f"g9_{tag}", sd=sd, x=x9, out=res[-1], first=res[0], keys=np.array(list(net.state_dict().keys())))
+        contract9[type(full).__name__] = np.array([f"{k}|{','.join(map(str, v.shape))}" for k, v in full.state_dict().items()])
+    save("g9_key_contract", **contract9)
+
     # ---- G7 Stage-I Bayesian U-Net, reduced width ----------------------------------------------
     print("G7 stage-I BNN")
     kw1 = dict(in_channels=3, out_channels=3, n_feat=16, stage=1, num_blocks=[2, 1, 1], d_state=[1, 1, 1], ssm_ratio=1,

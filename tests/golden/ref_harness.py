@@ -105,6 +105,9 @@ def load():
         ns.unet = importlib.import_module("basicsr.archs.UNet_arch")
         ns.ddw = importlib.import_module("basicsr.archs.DecompDualBranchDDWavelet_arch")
         ns.single = importlib.import_module("basicsr.archs.DecompSingleBranch_arch")
+        ns.dd = importlib.import_module("basicsr.archs.DecompDualBranchDD_arch")
+        ns.dual2 = importlib.import_module("basicsr.archs.DecompDualBranch_arch")
+        ns.singledd = importlib.import_module("basicsr.archs.DecompSingleBranchDD_arch")
     ns.torch = torch
     _loaded["ns"] = ns
     return ns

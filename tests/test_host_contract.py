@@ -131,3 +131,17 @@ def test_pad_and_downsample_host_logic():
     assert np.array_equal(p[0].permute(1, 2, 0).numpy(), ref)
     assert pad_to_multiple(torch.rand(1, 3, 128, 64), 64).shape == (1, 3, 128, 64)      # already a multiple: untouched
     assert torch.allclose(resize_down_linear(p, 16), O.cv2_resize_down(p, 16), atol=1e-7)
+
+
+@pytest.mark.parametrize("yml,arch", [("DecompDualBranch2DD_4.yml", "DecompDualBranch2DD"), ("DecompDualBranch2_1.yml", "DecompDualBranch2"),
+                                      ("DecompSingleBranchDD_1.yml", "DecompSingleBranchDD")])
+def test_sibling_arch_key_contract(yml, arch):
+    from basicsr.models import build_model
+    from basicsr.utils.options import parse
+    opt = parse(os.path.join(PKG, "Options", yml), is_train=False)
+    opt["num_gpu"] = 0
+    net = build_model(opt).net_g
+    assert type(net).__name__ == arch
+    ref = np.load(os.path.join(GOLDEN, "g9_key_contract.npz"))[arch].tolist()
+    mine = [f"{k}|{','.join(map(str, v.shape))}" for k, v in net.state_dict().items()]
+    assert sorted(mine) == sorted(ref)

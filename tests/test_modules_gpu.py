@@ -193,3 +193,20 @@ def test_stage2_config5_geometry_400x600():
     d = (out["final"][0].permute(1, 2, 0).cpu() - torch.from_numpy(ref["finals"][0])).abs()
     assert d.mean() < 1e-5 and d.max() < 2e-2, (d.mean(), d.max())
     assert abs(float(out["psnr"][0]) - ref["psnr"][0]) < 1e-3
+
+
+@pytest.mark.parametrize("tag,cls,dm", [("dualdd", "DecompDualBranch2DD", "model4"), ("dual2", "DecompDualBranch2", "model1"),
+                                        ("singledd", "DecompSingleBranchDD", "model1")])
+def test_sibling_archs_golden(tag, cls, dm):
+    """The three sibling Stage-II archs against the reference's own outputs (g9 fixtures); same kernels, other wiring."""
+    import bem.archs as A
+    g = load_golden(f"g9_{tag}")
+    net = getattr(A, cls)(in_channels=6, out_channels=3, n_feat=8, d_state=[1, 1, 1], ssm_ratio=1, mlp_ratio=4, mlp_type="gdmlp",
+                          use_pixelshuffle=True, drop_path=0.0, sam=False, stage=1, num_blocks=[1, 1, 1], decomp_model=dm)
+    assert set(net.state_dict().keys()) == set(g["keys"].tolist())
+    sd = dict(g["sd"]); sd.update({k: v for k, v in qd_state_dict(dm).items() if k in net.state_dict()})
+    net.load_state_dict(sd, strict=True)
+    net.cuda().eval()
+    res = net(g["x"].cuda())
+    close(res[-1], g["out"], 2e-3, 1e-4, cls)
+    close(res[0], g["first"], 0, 0, cls + " passthrough")

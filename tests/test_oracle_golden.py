@@ -98,3 +98,13 @@ def test_g8_eval_loop():
     close(np.stack(r["finals"]), g["finals"], rtol=1e-3, atol=1e-4)
     assert np.abs(np.array(r["psnr"]) - np.asarray(g["psnr"])).max() < 1e-3      # dB, the north-star parity bar
     assert r["best"] == int(g["best"])
+
+
+@pytest.mark.parametrize("tag,fn,dm", [("dualdd", O.dualbranch2dd_ref, "model4"), ("dual2", O.dualbranch2_ref, "model1"),
+                                       ("singledd", O.singlebranchdd_ref, "model1")])
+def test_g9_sibling_archs(tag, fn, dm):
+    """DecompDualBranch2DD / DecompDualBranch2 / DecompSingleBranchDD."""
+    g = load_golden(f"g9_{tag}")
+    sd = dict(g["sd"])
+    sd.update(qd_state_dict(dm))
+    close(fn(sd, g["x"], O.selective_scan_c), g["out"], rtol=1e-3, atol=2e-5)
