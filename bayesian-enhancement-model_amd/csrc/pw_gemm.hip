@@ -517,7 +517,10 @@ template <int MTW>
 __device__ __forceinline__ void pw3_epilogue(const PwK& k, int b, int mt0, int p, bool vec, int half,
                                              const f32x16 (&acc)[MTW][4]) {
     const float slope = (k.act == 1) ? k.prelu[0] : 0.f;
-    const float* bias = k.bias ? k.bias + (int64_t)b * k.bias_bstride : nullptr;
+    // bias through an always-valid pointer + multiplicative mask: per-row `bias ? bias[row] : 0` behind `row < M`
+    // compiles to a branch with a dependent load and a full vmcnt(0) wait for every row
+    const float* bias = k.bias ? k.bias + (int64_t)b * k.bias_bstride : k.Wp;
+    const float bmask = k.bias ? 1.f : 0.f;
 #pragma unroll
     for (int m = 0; m < MTW; ++m) {
         if (mt0 + m >= k.MT) continue;
@@ -525,12 +528,27 @@ __device__ __forceinline__ void pw3_epilogue(const PwK& k, int b, int mt0, int p
 #pragma unroll
         for (int rh = 0; rh < 16; rh += 4) {
             float4 rv[4];
-            if (k.res && k.out_mode == 0) {
+            float bv4[4];
 #pragma unroll
-                for (int r8 = 0; r8 < 4; ++r8) {
-                    const int r = rh + r8;
-                    const int row = rbase + (r & 3) + 8 * (r >> 2);
-                    rv[r8] = (row < k.M) ? ld4(k.res + ((int64_t)b * k.M + row) * k.L, p, k.L, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int r8 = 0; r8 < 4; ++r8) {
+                const int r = rh + r8;
+                bv4[r8] = bias[min(rbase + (r & 3) + 8 * (r >> 2), k.M - 1)] * bmask;
+            }
+            if (k.res && k.out_mode == 0) {
+                if (vec) {
+#pragma unroll
+                    for (int r8 = 0; r8 < 4; ++r8) {      // clamped row: unconditional loads, rows >= M are never stored
+                        const int r = rh + r8;
+                        const int row = min(rbase + (r & 3) + 8 * (r >> 2), k.M - 1);
+                        rv[r8] = *reinterpret_cast<const float4*>(k.res + ((int64_t)b * k.M + row) * k.L + p);
+                    }
+                } else {
+#pragma unroll
+                    for (int r8 = 0; r8 < 4; ++r8) {
+                        const int r = rh + r8;
+                        const int row = min(rbase + (r & 3) + 8 * (r >> 2), k.M - 1);
+                        rv[r8] = ld4(k.res + ((int64_t)b * k.M + row) * k.L, p, k.L, false);
+                    }
                 }
             }
 #pragma unroll
@@ -538,7 +556,7 @@ __device__ __forceinline__ void pw3_epilogue(const PwK& k, int b, int mt0, int p
                 const int r = rh + r8;
                 const int row = rbase + (r & 3) + 8 * (r >> 2);
                 if (row >= k.M) continue;
-                const float bv = bias ? bias[row] : 0.f;
+                const float bv = bv4[r8];
                 float o[4] = {acc[m][0][r] + bv, acc[m][1][r] + bv, acc[m][2][r] + bv, acc[m][3][r] + bv};
                 if (k.act == 1) {
 #pragma unroll
@@ -574,14 +592,23 @@ __device__ __forceinline__ void pw3_epilogue(const PwK& k, int b, int mt0, int p
 
 template <int KSM, int MTW, bool VEC, bool SUM>
 __global__ __launch_bounds__(256, (KSM > 20 ? 1 : 2)) void pw_gemm3_reg_kernel(PwK k) {
+    // LayerNorm scale / shift through LDS: read from global where they are used, each value costs an L1/L2 round trip
+    // in front of the dependent normalisation (20 serialized loads per wave in the ISA)
+    __shared__ float s_ln[4 * KSM];
+    for (int i = threadIdx.x; i < 2 * KSM; i += 256) {
+        const bool on = k.ln_w && i < k.K;
+        s_ln[i] = on ? k.ln_w[min(i, k.K - 1)] : 0.f;
+        s_ln[2 * KSM + i] = on ? k.ln_b[min(i, k.K - 1)] : 0.f;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
     const int b = blockIdx.z;
     const int p = (blockIdx.x * 4 + wave) * 128 + 4 * (lane & 31);
-    if (p - 4 * (lane & 31) >= k.L) return;
     const bool vec = (k.L % 4 == 0) && (p + 3 < k.L);
     const bool any = p < k.L;
     float4 xr[KSM];
     load_steps<KSM, VEC, SUM>(k, b, 0, half, p, any, xr);      // channels >= K come back as zeros
+    __syncthreads();                                            // s_ln visible (the only barrier; before any early exit)
+    if (p - 4 * (lane & 31) >= k.L) return;
     if (k.ln_w) {
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -593,10 +620,9 @@ __global__ __launch_bounds__(256, (KSM > 20 ? 1 : 2)) void pw_gemm3_reg_kernel(P
         float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int st = 0; st < KSM; ++st) {
-            if (2 * st + half < k.K) {
-                const float dx = xr[st].x - mean.x, dy = xr[st].y - mean.y, dz = xr[st].z - mean.z, dw = xr[st].w - mean.w;
-                q.x = fmaf(dx, dx, q.x); q.y = fmaf(dy, dy, q.y); q.z = fmaf(dz, dz, q.z); q.w = fmaf(dw, dw, q.w);
-            }
+            const float mk = (2 * st + half < k.K) ? 1.f : 0.f;                // padded channels do not count
+            const float dx = (xr[st].x - mean.x) * mk, dy = (xr[st].y - mean.y) * mk, dz = (xr[st].z - mean.z) * mk, dw = (xr[st].w - mean.w) * mk;
+            q.x = fmaf(dx, dx, q.x); q.y = fmaf(dy, dy, q.y); q.z = fmaf(dz, dz, q.z); q.w = fmaf(dw, dw, q.w);
         }
         q.x += __shfl_xor(q.x, 32, 64); q.y += __shfl_xor(q.y, 32, 64);
         q.z += __shfl_xor(q.z, 32, 64); q.w += __shfl_xor(q.w, 32, 64);
@@ -604,14 +630,11 @@ __global__ __launch_bounds__(256, (KSM > 20 ? 1 : 2)) void pw_gemm3_reg_kernel(P
                                         1.f / sqrtf(q.z * inv + k.ln_eps), 1.f / sqrtf(q.w * inv + k.ln_eps));
 #pragma unroll
         for (int st = 0; st < KSM; ++st) {
-            const int ch = 2 * st + half;
-            if (ch < k.K) {
-                const float g = k.ln_w[ch], be = k.ln_b[ch];
-                xr[st].x = (xr[st].x - mean.x) * rstd.x * g + be;
-                xr[st].y = (xr[st].y - mean.y) * rstd.y * g + be;
-                xr[st].z = (xr[st].z - mean.z) * rstd.z * g + be;
-                xr[st].w = (xr[st].w - mean.w) * rstd.w * g + be;
-            }
+            const float g = s_ln[2 * st + half], be = s_ln[2 * KSM + 2 * st + half];      // 0 on padded channels
+            xr[st].x = (xr[st].x - mean.x) * rstd.x * g + be;
+            xr[st].y = (xr[st].y - mean.y) * rstd.y * g + be;
+            xr[st].z = (xr[st].z - mean.z) * rstd.z * g + be;
+            xr[st].w = (xr[st].w - mean.w) * rstd.w * g + be;
         }
     }
     const float* wbase = k.Wp + (int64_t)b * k.w_bstride + lane;
@@ -627,7 +650,7 @@ __global__ __launch_bounds__(256, (KSM > 20 ? 1 : 2)) void pw_gemm3_reg_kernel(P
         const float* wp = wbase + (int64_t)mt0 * mt_stride;
         // No per-k-step branch (each would be its own basic block with the weight load pinned in front of its MFMAs);
         // steps beyond KS run on zero operands.  Weights arrive in batches of AB k-steps, one batch ahead.
-        constexpr int AB = 5;
+        constexpr int AB = 4;
         static_assert(KSM % AB == 0, "KSM must be a multiple of the weight batch");
         auto load_w = [&](int sb, float (&dst)[AB][MTW]) {
 #pragma unroll
