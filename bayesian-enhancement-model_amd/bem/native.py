@@ -75,6 +75,9 @@ SIGNATURES = {
     "bem_space_to_depth_f32": [P, P, I, I, I, I, P],
     "bem_pixel_shuffle2_f32": [P, P, I, I, I, I, P],
     "bem_bnn_sample_f32": [P, P, P, P, I, I64, U64, U64, P],
+    "bem_pad_reflect_f32": [P, P, I, I, I, I, I, P],
+    "bem_resize_down_f32": [P, P, I, I, I, I, P],
+    "bem_randn_f32": [P, I64, U64, U64, P],
     "bem_cond_postproc_f32": [P, P, P, P, I, I, I, I, F, P],
     "bem_plane_mean_f32": [P, P, I, I, I, I, I, P],
     "bem_candidate_finalize_f32": [P, P, P, P, P, I, I, I, I, I, I, I, P],

@@ -473,6 +473,32 @@ def bnn_sample(mu, rho, nsets, eps=None, seed=0, stream_id=0):
     return out
 
 
+def pad_reflect(x, Hp, Wp):
+    """(B,C,H,W) -> (B,C,Hp,Wp), reflect-padded at the bottom / right (numpy 'reflect')."""
+    _chk(x, "x")
+    B, C, H, W = x.shape
+    if Hp == H and Wp == W:
+        return x
+    out = torch.empty(B, C, Hp, Wp, device=x.device, dtype=x.dtype)
+    check(lib().bem_pad_reflect_f32(_p(x), _p(out), B * C, H, W, Hp, Wp, _stream()), "pad_reflect")
+    return out
+
+
+def resize_down(x, s):
+    """cv2.resize(fx=fy=1/s, INTER_LINEAR) of (B,C,Hp,Wp) planes for even s dividing Hp, Wp."""
+    _chk(x, "x")
+    B, C, Hp, Wp = x.shape
+    out = torch.empty(B, C, Hp // s, Wp // s, device=x.device, dtype=x.dtype)
+    check(lib().bem_resize_down_f32(_p(x), _p(out), B * C, Hp, Wp, s, _stream()), "resize_down")
+    return out
+
+
+def randn(shape, device, seed=0, stream_id=0):
+    out = torch.empty(shape, device=device, dtype=torch.float32)
+    check(lib().bem_randn_f32(_p(out), out.numel(), seed, stream_id, _stream()), "randn")
+    return out
+
+
 def plane_mean(x, h=None, w=None):
     """Mean over the top-left (h,w) window of every (b,c) plane -> (B,C)."""
     _chk(x, "x")

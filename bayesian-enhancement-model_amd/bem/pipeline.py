@@ -12,26 +12,9 @@ from __future__ import annotations
 from typing import Dict, List, Optional
 
 import torch
-import torch.nn.functional as F
 
 from . import ops
 from .modules import SampleCtx, sampling
-
-
-def pad_to_multiple(img: torch.Tensor, factor: int) -> torch.Tensor:
-    """_padimg_np (eval.py:146-153): reflect-pad bottom/right up to the next multiple of ``factor``.
-    Host-side image preparation in the reference (numpy); a torch indexing op here."""
-    h, w = img.shape[-2:]
-    ph = (((h + factor) // factor) * factor - h) if h % factor else 0
-    pw = (((w + factor) // factor) * factor - w) if w % factor else 0
-    return F.pad(img, (0, pw, 0, ph), mode="reflect") if (ph or pw) else img
-
-
-def resize_down_linear(img: torch.Tensor, s: int) -> torch.Tensor:
-    """cv2.resize(fx=fy=1/s, INTER_LINEAR) for even s on H, W multiples of s (eval.py:174): the mean of
-    the 2x2 centre taps of every s x s cell.  cv2 is unavailable here -> parity unpinned (oracle docstring)."""
-    a = s // 2 - 1
-    return 0.25 * (img[..., a::s, a::s] + img[..., a + 1::s, a::s] + img[..., a::s, a + 1::s] + img[..., a + 1::s, a + 1::s])
 
 
 class BEMPipeline:
@@ -50,17 +33,20 @@ class BEMPipeline:
         from basicsr.bayesian import set_prediction_type
         B, _, h, w = imgs.shape
         N = 1 if deterministic else num_samples
-        pad = pad_to_multiple(imgs, 4 * self.scale).contiguous()
-        Hp, Wp = pad.shape[-2:]
+        f = 4 * self.scale
+        Hp = (((h + f) // f) * f) if h % f else h                                # _padimg_np, eval.py:146-153
+        Wp = (((w + f) // f) * f) if w % f else w
+        pad = ops.pad_reflect(imgs.contiguous(), Hp, Wp)
         if img_down is None:
-            img_down = resize_down_linear(pad, self.scale)
-        x1 = img_down.repeat_interleave(N, dim=0).contiguous()                   # (B*N,3,hd,wd)
+            img_down = ops.resize_down(pad, self.scale)
+        hd, wd = img_down.shape[-2:]
+        x1 = img_down[:, None].expand(B, N, 3, hd, wd).reshape(B * N, 3, hd, wd)  # (B*N,3,hd,wd): row = image*N + sample
         set_prediction_type(self.net1, deterministic)
         with sampling(None if deterministic else SampleCtx(B * N, eps, seed)):
             pred = self.net1(x1)[-1]
         tmean = ops.plane_mean(targets.contiguous()) if (gt_mean and targets is not None) else None
         if noise is None and self.noise_level:
-            noise = torch.randn(pred.shape, device=pred.device, dtype=pred.dtype)
+            noise = ops.randn(tuple(pred.shape), pred.device, seed, (1 << 40) + SampleCtx._epoch)   # torch.randn_like of eval.py:209
         conds = ops.cond_postproc(pred, tmean, noise if self.noise_level else None, N, self.noise_level)
         cond_up = ops.bilinear_up(conds, self.scale)                             # (B*N,3,Hp,Wp)
         d_img = self.net2.decompose(pad, 0)                                      # once per image

@@ -96,6 +96,93 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
     }
 }
 
+// Fast form for W % 4 == 0, 64 % (W/4) == 0, H % RB == 0 (every plane of a 256x256 image): a wavefront covers whole
+// image rows, so the left / right halo columns come from the neighbouring lanes' float4 (DPP wave shifts) instead of
+// two more loads per row; rows are read at clamped addresses and the two possibly-outside rows are masked by
+// multiplication, so the RB + 2 row loads of a plane issue back to back with no branch in between.
+__device__ __forceinline__ float dpp_from_prev_lane(float v) {   // lane l <- lane l - 1 (lane 0 <- 0.f)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_from_next_lane(float v) {   // lane l <- lane l + 1 (lane 63 <- 0.f)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
+__device__ __forceinline__ void dw_block_fast(const float* __restrict__ plane, int H, int W, int y0, int x0,
+                                              const float* __restrict__ w9, float (&acc)[RB][4]) {
+    float4 c[RB + 2];
+#pragma unroll
+    for (int ry = -1; ry <= RB; ++ry) {
+        const int yy = min(max(y0 + ry, 0), H - 1);
+        c[ry + 1] = *reinterpret_cast<const float4*>(plane + (int64_t)yy * W + x0);
+    }
+    float wk[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wk[i] = w9[i];
+    const float mt = y0 > 0 ? 1.f : 0.f, mb = y0 + RB < H ? 1.f : 0.f;
+    const float ml = x0 > 0 ? 1.f : 0.f, mr = x0 + 4 < W ? 1.f : 0.f;
+#pragma unroll
+    for (int ry = -1; ry <= RB; ++ry) {
+        float4 q = c[ry + 1];
+        if (ry == -1) { q.x *= mt; q.y *= mt; q.z *= mt; q.w *= mt; }
+        if (ry == RB) { q.x *= mb; q.y *= mb; q.z *= mb; q.w *= mb; }
+        const float v[6] = {dpp_from_prev_lane(q.w) * ml, q.x, q.y, q.z, q.w, dpp_from_next_lane(q.x) * mr};
+#pragma unroll
+        for (int oy = 0; oy < RB; ++oy) {
+            const int dy = ry - oy;
+            if (dy < -1 || dy > 1) continue;
+            const float w0 = wk[(dy + 1) * 3], w1 = wk[(dy + 1) * 3 + 1], w2 = wk[(dy + 1) * 3 + 2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[oy][j] = fmaf(w0, v[j], fmaf(w1, v[j + 1], fmaf(w2, v[j + 2], acc[oy][j])));
+        }
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void dwconv3x3_fast_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             int64_t w_bs, const float* __restrict__ bias, int64_t b_bs,
+                                                             float* __restrict__ out, int Cout, int H, int W) {
+    const int W4 = W >> 2, HB = H / RB;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HB * W4) return;           // whole rows per wavefront: the lanes that leave are past the last row
+    const int yb = i / W4, y0 = yb * RB, x0 = (i - yb * W4) * 4;
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int Cin = (MODE == 2) ? 2 * Cout : Cout;
+    const int64_t HW = (int64_t)H * W;
+    const float* wb = w + (int64_t)b * w_bs;
+    // bias through an always-valid pointer and a multiplicative mask (no branch around the load)
+    const float* bb = bias ? bias + (int64_t)b * b_bs : wb;
+    const float bm = bias ? 1.f : 0.f;
+    const float b0 = bb[bias ? c : 0] * bm;
+    const float b1 = (MODE == 2) ? bb[bias ? c + Cout : 0] * bm : 0.f;
+    const float* pl = x + ((int64_t)b * Cin + c) * HW;
+    float a0[RB][4], a1[RB][4];
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a0[r][j] = a1[r][j] = 0.f;
+    dw_block_fast(pl, H, W, y0, x0, wb + (int64_t)c * 9, a0);
+    if (MODE == 2) dw_block_fast(x + ((int64_t)b * Cin + c + Cout) * HW, H, W, y0, x0, wb + (int64_t)(c + Cout) * 9, a1);
+    float4 self[RB];
+    if (MODE == 3) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) self[r] = *reinterpret_cast<const float4*>(pl + (int64_t)(y0 + r) * W + x0);
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        float o[4];
+        const float sv[4] = {MODE == 3 ? self[r].x : 0.f, MODE == 3 ? self[r].y : 0.f, MODE == 3 ? self[r].z : 0.f, MODE == 3 ? self[r].w : 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = a0[r][j] + b0;
+            if (MODE == 2) o[j] = bem_gelu_fast(v) * (a1[r][j] + b1);
+            else if (MODE == 1) o[j] = bem_silu(v);
+            else if (MODE == 3) o[j] = sv[j] + fmaxf(v, 0.f);
+            else o[j] = v;
+        }
+        *reinterpret_cast<float4*>(out + ((int64_t)b * Cout + c) * HW + (int64_t)(y0 + r) * W + x0) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // dense direct conv.  Workgroup = 256 threads = 8 x 32 output pixels, COB output channels per
 // workgroup, input channels streamed through LDS in chunks of CIB (patch + weights).
@@ -317,7 +404,13 @@ extern "C" int bem_dwconv3x3_f32(const float* x, const float* w, int64_t w_bstri
     BEM_REQUIRE(mode >= 0 && mode <= 3, "dwconv3x3: mode %d", mode);
     if (B == 0) return BEM_OK;
     dim3 grid(cdiv(cdiv(H, RB) * ((W + 3) / 4), 256), Cout, B);
-    dwconv3x3_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, w, w_bstride, bias, bias_bstride, out, Cout, H, W, mode);
+    hipStream_t s = (hipStream_t)stream;
+    const bool fast = W % 4 == 0 && 64 % (W / 4) == 0 && H % RB == 0 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0;
+    if (!fast) dwconv3x3_kernel<<<grid, 256, 0, s>>>(x, w, w_bstride, bias, bias_bstride, out, Cout, H, W, mode);
+    else if (mode == 0) dwconv3x3_fast_kernel<0><<<grid, 256, 0, s>>>(x, w, w_bstride, bias, bias_bstride, out, Cout, H, W);
+    else if (mode == 1) dwconv3x3_fast_kernel<1><<<grid, 256, 0, s>>>(x, w, w_bstride, bias, bias_bstride, out, Cout, H, W);
+    else if (mode == 2) dwconv3x3_fast_kernel<2><<<grid, 256, 0, s>>>(x, w, w_bstride, bias, bias_bstride, out, Cout, H, W);
+    else dwconv3x3_fast_kernel<3><<<grid, 256, 0, s>>>(x, w, w_bstride, bias, bias_bstride, out, Cout, H, W);
     return bem_check_launch("dwconv3x3");
 }
 

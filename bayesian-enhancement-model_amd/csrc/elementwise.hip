@@ -380,6 +380,33 @@ __global__ void pixel_shuffle2_kernel(const float* __restrict__ x, float* __rest
     out[i] = x[(((int64_t)b * 4 * C + ch) * H + (yo >> 1)) * W + (xo >> 1)];
 }
 
+// ---------------------------------------------------------------- eval.py image preparation --
+// reflect-pad bottom/right to (Hp, Wp) (numpy 'reflect': edge pixel not repeated, eval.py:146-153) fused with the
+// x1/s INTER_LINEAR condition (eval.py:174): for even s the bilinear taps of output (i, j) are the four pixels
+// (s*i + s/2 - 1 .. s*i + s/2, s*j + s/2 - 1 .. s*j + s/2) of the padded image, weight 1/4 each.
+__device__ __forceinline__ int reflect_idx(int i, int n) { return i < n ? i : 2 * (n - 1) - i; }
+
+__global__ void pad_reflect_kernel(const float* __restrict__ x, float* __restrict__ out, int H, int W, int Hp, int Wp,
+                                   int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int xo = (int)(i % Wp), yo = (int)((i / Wp) % Hp);
+    const int64_t plane = i / ((int64_t)Wp * Hp);
+    out[i] = x[(plane * H + reflect_idx(yo, H)) * W + reflect_idx(xo, W)];
+}
+
+__global__ void resize_down_kernel(const float* __restrict__ x, float* __restrict__ out, int Hp, int Wp, int s,
+                                   int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int wd = Wp / s, hd = Hp / s;
+    const int xo = (int)(i % wd), yo = (int)((i / wd) % hd);
+    const int64_t plane = i / ((int64_t)wd * hd);
+    const int a = s / 2 - 1;
+    const float* p = x + (plane * Hp + (int64_t)yo * s + a) * Wp + (int64_t)xo * s + a;
+    out[i] = 0.25f * (p[0] + p[Wp] + p[1] + p[Wp + 1]);
+}
+
 // ---------------------------------------------------------------- Bayesian sampling ----------
 __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
 #pragma unroll
@@ -392,6 +419,19 @@ __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uin
     }
 }
 
+__device__ __forceinline__ float philox_normal(int64_t i, uint64_t seed, uint64_t stream_id) {
+    uint32_t c[4] = {(uint32_t)i, (uint32_t)((uint64_t)i >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float u1 = ((float)(c[0] >> 8) + 1.0f) * (1.0f / 16777216.0f);   // (0, 1]
+    const float u2 = (float)(c[1] >> 8) * (1.0f / 16777216.0f);            // [0, 1)
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);   // Box-Muller
+}
+
+__global__ void randn_kernel(float* __restrict__ out, int64_t total, uint64_t seed, uint64_t stream_id) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) out[i] = philox_normal(i, seed, stream_id);
+}
+
 __global__ void bnn_sample_kernel(const float* __restrict__ mu, const float* __restrict__ rho,
                                   const float* __restrict__ eps_in, float* __restrict__ out, int64_t n, int64_t total,
                                   uint64_t seed, uint64_t stream_id) {
@@ -402,11 +442,7 @@ __global__ void bnn_sample_kernel(const float* __restrict__ mu, const float* __r
     if (eps_in) {
         eps = eps_in[i];
     } else {
-        uint32_t c[4] = {(uint32_t)i, (uint32_t)((uint64_t)i >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
-        philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-        const float u1 = ((float)(c[0] >> 8) + 1.0f) * (1.0f / 16777216.0f);   // (0, 1]
-        const float u2 = (float)(c[1] >> 8) * (1.0f / 16777216.0f);            // [0, 1)
-        eps = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);    // Box-Muller
+        eps = philox_normal(i, seed, stream_id);
     }
     out[i] = mu[e] + log1pf(expf(rho[e])) * eps;
 }
@@ -688,4 +724,29 @@ extern "C" int bem_candidate_finalize_f32(const float* pred, const float* target
     cand_final_kernel<<<grid, 256, 0, s>>>(pred, target, final_out, ws, samples_per_image, Hp, Wp, h, w, gt_mean);
     if (psnr) cand_psnr_kernel<<<cdiv(Bn, 256), 256, 0, s>>>(ws, psnr, Bn, (int64_t)h * w, target != nullptr);
     return bem_check_launch("candidate_finalize");
+}
+
+extern "C" int bem_pad_reflect_f32(const float* x, float* out, int P, int H, int W, int Hp, int Wp, void* stream) {
+    BEM_REQUIRE(x && out, "pad_reflect: null tensor");
+    BEM_REQUIRE(P >= 0 && H > 0 && W > 0 && Hp >= H && Wp >= W && Hp - H < H && Wp - W < W, "pad_reflect: pad must be smaller than the image");
+    const int64_t total = (int64_t)P * Hp * Wp;
+    if (total == 0) return BEM_OK;
+    pad_reflect_kernel<<<GRID1D(total), 256, 0, (hipStream_t)stream>>>(x, out, H, W, Hp, Wp, total);
+    return bem_check_launch("pad_reflect");
+}
+
+extern "C" int bem_resize_down_f32(const float* x, float* out, int P, int Hp, int Wp, int s, void* stream) {
+    BEM_REQUIRE(x && out, "resize_down: null tensor");
+    BEM_REQUIRE(P >= 0 && s >= 2 && s % 2 == 0 && Hp > 0 && Wp > 0 && Hp % s == 0 && Wp % s == 0, "resize_down: even factor dividing H and W required");
+    const int64_t total = (int64_t)P * (Hp / s) * (Wp / s);
+    if (total == 0) return BEM_OK;
+    resize_down_kernel<<<GRID1D(total), 256, 0, (hipStream_t)stream>>>(x, out, Hp, Wp, s, total);
+    return bem_check_launch("resize_down");
+}
+
+extern "C" int bem_randn_f32(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream) {
+    BEM_REQUIRE(out && n >= 0, "randn: bad arguments");
+    if (n == 0) return BEM_OK;
+    randn_kernel<<<GRID1D(n), 256, 0, (hipStream_t)stream>>>(out, n, seed, stream_id);
+    return bem_check_launch("randn");
 }

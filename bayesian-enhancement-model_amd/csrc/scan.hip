@@ -20,9 +20,9 @@ __device__ __forceinline__ float shfl_prev(float v, int d) {
 // coefficients h_t = a_t * h_prev + b_t of this thread's E positions (identity = (1, 0) for padding).
 // On exit h[e] holds the state after position e; `carry` (state entering the chunk, uniform) is updated
 // to the state leaving the chunk.  agg is LDS scratch of 2*NW floats; contains two barriers.
+// block_scan_enter returns the state entering this thread's first position (in scan order) and advances `carry`.
 template <int NT, int E, bool REV>
-__device__ __forceinline__ void block_scan_affine(const float (&a)[E], const float (&b)[E], float (&h)[E],
-                                                  float& carry, float* agg) {
+__device__ __forceinline__ float block_scan_enter(const float (&a)[E], const float (&b)[E], float& carry, float* agg) {
     constexpr int NW = NT / BEM_WAVE;
     const int lane = threadIdx.x & (BEM_WAVE - 1);
     const int wave = threadIdx.x / BEM_WAVE;
@@ -69,14 +69,20 @@ __device__ __forceinline__ void block_scan_affine(const float (&a)[E], const flo
         const float St = __shfl(S, REV ? 0 : BEM_WAVE - 1, BEM_WAVE);
         hend = Pt * carry + St;
     }
-    float hh = Pe * hw + Se;   // state entering this thread
+    carry = hend;
+    return Pe * hw + Se;       // state entering this thread
+}
+
+template <int NT, int E, bool REV>
+__device__ __forceinline__ void block_scan_affine(const float (&a)[E], const float (&b)[E], float (&h)[E],
+                                                  float& carry, float* agg) {
+    float hh = block_scan_enter<NT, E, REV>(a, b, carry, agg);
 #pragma unroll
     for (int i = 0; i < E; ++i) {
         const int e = REV ? (E - 1 - i) : i;
         hh = a[e] * hh + b[e];
         h[e] = hh;
     }
-    carry = hend;
 }
 
 template <int E>
@@ -358,9 +364,14 @@ __global__ __launch_bounds__(NT) void ss2d_scan_kernel(
     const float* __restrict__ x0, const float* __restrict__ x1, const float* __restrict__ xd0,
     const float* __restrict__ xd1, const float* __restrict__ dtw, const float* __restrict__ dtb,
     const float* __restrict__ A, const float* __restrict__ Ds, float* __restrict__ y0,
-    float* __restrict__ y1, int C, int L, int R) {
+    float* __restrict__ y1, int Bn, int C, int L, int R) {
     __shared__ float agg[2 * (NT / BEM_WAVE)];
-    const int c = blockIdx.x, b = blockIdx.y, o = blockIdx.z;
+    // XCD-aware order: workgroup ids are dealt round-robin to the 8 XCDs, so give each XCD a contiguous range of
+    // (orientation, image, channel) work items -- the C channel rows of one (o, b) share its 2*(R+2) x_dbl planes in that XCD's L2.
+    const int total = gridDim.x, lin = blockIdx.x;
+    const int per = total / 8, rem = total % 8, xcd = lin % 8, idx = lin / 8;
+    const int wi = xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
+    const int c = wi % C, b = (wi / C) % Bn, o = wi / (C * Bn);
     const float* xr = (o ? x1 : x0) + ((int64_t)b * C + c) * L;
     const float* xd = (o ? xd1 : xd0) + (int64_t)b * 2 * (R + 2) * L;
     float* yr = (o ? y1 : y0) + ((int64_t)b * C + c) * L;
@@ -400,6 +411,102 @@ __global__ __launch_bounds__(NT) void ss2d_scan_kernel(
         for (int e = 0; e < E; ++e) yv[e] = yacc[e] + fmaf(cv[e], h[e], Dr * x[e]);
         store_row<E>(yr, t0, L, vec, yv);
     }
+}
+
+// Whole-row form for L == NT * E (the 128x128 / 64x64 / 32x32 planes of a 256x256 image): x, the forward result and the
+// reverse result stay in registers, so x is read once and y written once; no bounds masks.  C_t is reloaded from the
+// (L2-resident) x_dbl plane after the scan instead of being held across it.
+template <int E>
+__device__ __forceinline__ void ss2d_coeffs_full(const float* __restrict__ xd, const float* __restrict__ wdt, float dtb,
+                                                 float Ak, const float (&x)[E], int t0, int L, int R, float (&a)[E],
+                                                 float (&b)[E]) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) a[e] = dtb;
+    for (int r = 0; r < R; ++r) {
+        const float w = wdt[r];
+#pragma unroll
+        for (int i = 0; i < E; i += 4) {
+            const float4 q = *reinterpret_cast<const float4*>(xd + (int64_t)r * L + t0 + i);
+            a[i] = fmaf(w, q.x, a[i]); a[i + 1] = fmaf(w, q.y, a[i + 1]);
+            a[i + 2] = fmaf(w, q.z, a[i + 2]); a[i + 3] = fmaf(w, q.w, a[i + 3]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < E; i += 4) {
+        const float4 q = *reinterpret_cast<const float4*>(xd + (int64_t)R * L + t0 + i);
+        const float bv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float dl = bem_softplus(a[i + j]);
+            a[i + j] = bem_fexp(dl * Ak);
+            b[i + j] = dl * bv[j] * x[i + j];
+        }
+    }
+}
+
+template <int NT, int E>
+__global__ __launch_bounds__(NT) void ss2d_scan_full_kernel(
+    const float* __restrict__ x0, const float* __restrict__ x1, const float* __restrict__ xd0,
+    const float* __restrict__ xd1, const float* __restrict__ dtw, const float* __restrict__ dtb,
+    const float* __restrict__ A, const float* __restrict__ Ds, float* __restrict__ y0,
+    float* __restrict__ y1, int Bn, int C, int R) {
+    __shared__ float agg[2 * (NT / BEM_WAVE)];
+    constexpr int L = NT * E;
+    const int total = gridDim.x, lin = blockIdx.x;      // XCD-aware order, as in ss2d_scan_kernel
+    const int per = total / 8, rem = total % 8, xcd = lin % 8, idx = lin / 8;
+    const int wi = xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
+    const int c = wi % C, b = (wi / C) % Bn, o = wi / (C * Bn);
+    const float* xr = (o ? x1 : x0) + ((int64_t)b * C + c) * L;
+    const float* xd = (o ? xd1 : xd0) + (int64_t)b * 2 * (R + 2) * L;
+    float* yr = (o ? y1 : y0) + ((int64_t)b * C + c) * L;
+    const int kf = o, kr = o + 2;
+    const int t0 = threadIdx.x * E;
+    float x[E], y[E];
+#pragma unroll
+    for (int i = 0; i < E; i += 4) {
+        const float4 q = *reinterpret_cast<const float4*>(xr + t0 + i);
+        x[i] = q.x; x[i + 1] = q.y; x[i + 2] = q.z; x[i + 3] = q.w;
+    }
+    {
+        float a[E], bb[E];
+        ss2d_coeffs_full<E>(xd, dtw + ((int64_t)kf * C + c) * R, dtb[kf * C + c], A[kf * C + c], x, t0, L, R, a, bb);
+        float carry = 0.f;
+        float hh = block_scan_enter<NT, E, false>(a, bb, carry, agg);
+        const float Df = Ds[kf * C + c];
+        const float* cp = xd + (int64_t)(R + 1) * L + t0;
+#pragma unroll
+        for (int i = 0; i < E; i += 4) {
+            const float4 q = *reinterpret_cast<const float4*>(cp + i);
+            const float cv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                hh = a[i + j] * hh + bb[i + j];
+                y[i + j] = fmaf(cv[j], hh, Df * x[i + j]);
+            }
+        }
+    }
+    {
+        float a[E], bb[E];
+        const float* xdr = xd + (int64_t)(R + 2) * L;
+        ss2d_coeffs_full<E>(xdr, dtw + ((int64_t)kr * C + c) * R, dtb[kr * C + c], A[kr * C + c], x, t0, L, R, a, bb);
+        float carry = 0.f;
+        float hh = block_scan_enter<NT, E, true>(a, bb, carry, agg);
+        const float Dr = Ds[kr * C + c];
+        const float* cp = xdr + (int64_t)(R + 1) * L + t0;
+#pragma unroll
+        for (int i = E - 4; i >= 0; i -= 4) {
+            const float4 q = *reinterpret_cast<const float4*>(cp + i);
+            const float cv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int j = 3; j >= 0; --j) {
+                hh = a[i + j] * hh + bb[i + j];
+                y[i + j] += fmaf(cv[j], hh, Dr * x[i + j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < E; i += 4)
+        *reinterpret_cast<float4*>(yr + t0 + i) = make_float4(y[i], y[i + 1], y[i + 2], y[i + 3]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -462,16 +569,23 @@ extern "C" int bem_ss2d_scan_f32(const float* x0, const float* x1, const float* 
                                  const float* dtw, const float* dtb, const float* A, const float* Ds, float* y0,
                                  float* y1, int B, int C, int L, int R, void* stream) {
     BEM_REQUIRE(x0 && x1 && xd0 && xd1 && dtw && dtb && A && Ds && y0 && y1, "ss2d_scan: null tensor");
-    BEM_REQUIRE(B >= 0 && B <= 65535 && C > 0 && L >= 0 && R >= 1, "ss2d_scan: bad shape B=%d C=%d L=%d R=%d", B, C, L, R);
+    BEM_REQUIRE(B >= 0 && C > 0 && L >= 0 && R >= 1 && (int64_t)B * C * 2 < (1ll << 31), "ss2d_scan: bad shape B=%d C=%d L=%d R=%d", B, C, L, R);
     if (B == 0 || L == 0) return BEM_OK;
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(C, B, 2);
-    if (L <= 256)
-        ss2d_scan_kernel<64, 4><<<grid, 64, 0, s>>>(x0, x1, xd0, xd1, dtw, dtb, A, Ds, y0, y1, C, L, R);
-    else if (L <= 1024)
-        ss2d_scan_kernel<128, 8><<<grid, 128, 0, s>>>(x0, x1, xd0, xd1, dtw, dtb, A, Ds, y0, y1, C, L, R);
-    else
-        ss2d_scan_kernel<256, 8><<<grid, 256, 0, s>>>(x0, x1, xd0, xd1, dtw, dtb, A, Ds, y0, y1, C, L, R);
+    const int grid = C * B * 2;
+#define BEM_SS2D(NT, E) ss2d_scan_kernel<NT, E><<<grid, NT, 0, s>>>(x0, x1, xd0, xd1, dtw, dtb, A, Ds, y0, y1, B, C, L, R)
+#define BEM_SS2D_FULL(NT, E) ss2d_scan_full_kernel<NT, E><<<grid, NT, 0, s>>>(x0, x1, xd0, xd1, dtw, dtb, A, Ds, y0, y1, B, C, R)
+    const bool al = (((uintptr_t)x0 | (uintptr_t)x1 | (uintptr_t)xd0 | (uintptr_t)xd1 | (uintptr_t)y0 | (uintptr_t)y1) & 15) == 0;
+    // whole-row forms: x read once, y written once.  (A 1024 x 16 form for L = 16384 measured slower than the chunked
+    // kernel -- 128-VGPR budget, 2 workgroups per CU -- so rows longer than 4096 stay on the chunked path.)
+    if (al && L == 4096) BEM_SS2D_FULL(512, 8);
+    else if (al && L == 1024) BEM_SS2D_FULL(128, 8);
+    else if (al && L == 256) BEM_SS2D_FULL(64, 4);
+    else if (L <= 256) BEM_SS2D(64, 4);
+    else if (L <= 1024) BEM_SS2D(128, 8);
+    else BEM_SS2D(256, 8);
+#undef BEM_SS2D
+#undef BEM_SS2D_FULL
     return bem_check_launch("ss2d_scan");
 }
 

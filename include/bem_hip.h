@@ -199,6 +199,12 @@ int bem_pixel_shuffle2_f32(const float* x, float* out, int B, int C, int H, int 
  * Philox4x32-10 N(0,1) draw keyed by (seed, stream_id, s*n + i). */
 int bem_bnn_sample_f32(const float* mu, const float* rho, const float* eps_in, float* out,
                        int nsets, int64_t n, uint64_t seed, uint64_t stream_id, void* stream);
+/* Image preparation of eval.py:146-176: reflect-pad bottom/right of P planes (H,W) -> (Hp,Wp) (numpy 'reflect'), and the
+ * x1/s INTER_LINEAR condition image of the padded planes (even s dividing Hp, Wp): mean of the 2x2 centre taps. */
+int bem_pad_reflect_f32(const float* x, float* out, int P, int H, int W, int Hp, int Wp, void* stream);
+int bem_resize_down_f32(const float* x, float* out, int P, int Hp, int Wp, int s, void* stream);
+/* N(0,1) draws from the same Philox4x32-10 stream family as bem_bnn_sample_f32 (torch.randn_like of eval.py:209). */
+int bem_randn_f32(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream);
 /* Stage-I post-processing (eval.py:200-209): c = clamp(pred,0,1); if target_mean: c = clamp(c *
  * target_mean[b_img][ch] / mean_hw(c), 0, 1); c += noise * noise_level.  pred/out (Bn,3,h,w);
  * target_mean (n_img,3) with image index = b / samples_per_image; noise may be NULL. */

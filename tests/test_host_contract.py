@@ -121,18 +121,6 @@ def test_bnn_conversion_and_prediction_type():
     assert "subnets.0.bottleneck.blocks.0.op.x_proj_weight" in keys
 
 
-def test_pad_and_downsample_host_logic():
-    from bem.pipeline import pad_to_multiple, resize_down_linear
-    from oracle import bem_oracle as O
-    x = torch.rand(1, 3, 60, 52)
-    p = pad_to_multiple(x, 64)
-    assert p.shape == (1, 3, 64, 64)
-    ref = O.pad_reflect_ref(x[0].permute(1, 2, 0).numpy(), 64)
-    assert np.array_equal(p[0].permute(1, 2, 0).numpy(), ref)
-    assert pad_to_multiple(torch.rand(1, 3, 128, 64), 64).shape == (1, 3, 128, 64)      # already a multiple: untouched
-    assert torch.allclose(resize_down_linear(p, 16), O.cv2_resize_down(p, 16), atol=1e-7)
-
-
 @pytest.mark.parametrize("yml,arch", [("DecompDualBranch2DD_4.yml", "DecompDualBranch2DD"), ("DecompDualBranch2_1.yml", "DecompDualBranch2"),
                                       ("DecompSingleBranchDD_1.yml", "DecompSingleBranchDD")])
 def test_sibling_arch_key_contract(yml, arch):

