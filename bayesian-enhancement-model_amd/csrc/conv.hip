@@ -1,6 +1,7 @@
 // Spatial convolutions: depthwise 3x3 (with fused SiLU / gated-GELU / PostSmooth epilogues) and a
 // dense direct convolution (3x3 s1, 4x4 s2, ...) staged through LDS.
 #include "bem_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -272,8 +273,63 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const float* __restrict__ x
 // ------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// LDS offset of implicit-GEMM row k = (channel-in-chunk, ky, kx) inside the staged patch: a compile-time constant in the
+// unrolled k loops (the two halves of a wavefront take k = 2 s and 2 s + 1), so no table lookup sits in front of the reads.
+template <int KH, int KW, int PH, int PWP>
+__device__ __forceinline__ constexpr int patch_off(int k) {
+    return (k / (KH * KW)) * PH * PWP + ((k % (KH * KW)) / KW) * PWP + (k % (KH * KW)) % KW;
+}
+
+// epilogue: out = relu?(acc + bias) + res1 + res2.  Optional operands are read through an always-valid pointer (the
+// packed weights, finite) at index 0 and masked by multiplication, rows / pixels past the edge at clamped indices, so
+// the loads carry no branches; only the stores are predicated.
+template <int MTW>
+__device__ __forceinline__ void conv_mfma_epilogue(f32x16 (&acc)[MTW][2], const float* __restrict__ Wp, const float* __restrict__ bias,
+                                                   const float* __restrict__ res1, const float* __restrict__ res2,
+                                                   float* __restrict__ out, int b, int Cout, int Ho, int Wo, int ty0, int tx0,
+                                                   int wave, int half, int j, int relu) {
+    const int ox = tx0 + j, oxc = min(ox, Wo - 1);
+    const float* bp = bias ? bias : Wp;
+    const float* p1 = res1 ? res1 : Wp;
+    const float* p2 = res2 ? res2 : Wp;
+    const float bmk = bias ? 1.f : 0.f, m1 = res1 ? 1.f : 0.f, m2 = res2 ? 1.f : 0.f;
+    const int64_t k0 = bias ? -1 : 0, k1 = res1 ? -1 : 0, k2 = res2 ? -1 : 0;     // index masks
+    const float lo = relu ? 0.f : -3.402823466e38f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int oy = ty0 + 2 * wave + t, oyc = min(oy, Ho - 1);
+        const bool pix = oy < Ho && ox < Wo;
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            constexpr int RG = 8;                          // rows per load batch (register budget)
+#pragma unroll
+            for (int r0 = 0; r0 < 16; r0 += RG) {
+                float r1[RG], r2[RG], bv[RG];
+#pragma unroll
+                for (int q = 0; q < RG; ++q) {
+                    const int r = r0 + q;
+                    const int co = min(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, Cout - 1);
+                    const int64_t idx = (((int64_t)b * Cout + co) * Ho + oyc) * Wo + oxc;
+                    bv[q] = bp[co & k0] * bmk;
+                    r1[q] = p1[idx & k1] * m1;
+                    r2[q] = p2[idx & k2] * m2;
+                }
+#pragma unroll
+                for (int q = 0; q < RG; ++q) {
+                    const int r = r0 + q;
+                    const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (pix && co < Cout)
+                        out[(((int64_t)b * Cout + co) * Ho + oy) * Wo + ox] = fmaxf(acc[m][t][r] + bv[q], lo) + r1[q] + r2[q];
+                }
+            }
+        }
+    }
+}
+
+// second launch bound = wavefronts per SIMD the register allocation must leave room for: without it the compiler spreads a
+// 32-accumulator kernel over 190 registers and two workgroups fill a CU
 template <int KH, int KW, int S, int MTW>
-__global__ __launch_bounds__(256) void conv2d_mfma_kernel(const float* __restrict__ x, int64_t x_bs,
+__global__ __launch_bounds__(256, MTW == 1 ? 4 : MTW == 2 ? 3 : MTW == 3 ? 2 : 1) void conv2d_mfma_kernel(const float* __restrict__ x, int64_t x_bs,
                                                           const float* __restrict__ Wp, const float* __restrict__ bias,
                                                           const float* __restrict__ res1, const float* __restrict__ res2,
                                                           float* __restrict__ out, int Cin, int H, int W, int Cout,
@@ -282,16 +338,11 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(const float* __restric
     constexpr int KC = CIB * KK;                          // k values per chunk (even)
     constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW, PWP = PW + 1;
     __shared__ float patch[CIB * PH * PWP];
-    __shared__ int offs[KC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, j = lane & 31;
     const int tile = blockIdx.x, b = blockIdx.y;
     const int ty0 = (tile / tilesX) * TH, tx0 = (tile % tilesX) * TW;
     const int iy0 = ty0 * S - pad, ix0 = tx0 * S - pad;
     const float* xb = x + (int64_t)b * x_bs;
-    for (int i = threadIdx.x; i < KC; i += 256) {
-        const int cc = i / KK, t = i - cc * KK;
-        offs[i] = cc * PH * PWP + (t / KW) * PWP + (t % KW);
-    }
     f32x16 acc[MTW][2];
 #pragma unroll
     for (int m = 0; m < MTW; ++m)
@@ -304,7 +355,7 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(const float* __restric
     const int rowoff0 = (2 * wave) * S * PWP + j * S, rowoff1 = rowoff0 + S * PWP;
 
     for (int ci0 = 0; ci0 < Cin; ci0 += CIB) {
-        __syncthreads();                                  // previous chunk fully consumed (also covers offs on the first pass)
+        __syncthreads();                                  // previous chunk fully consumed
         {
             constexpr int UB = 8;
             constexpr int TOT = CIB * PH * PW;
@@ -353,7 +404,8 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(const float* __restric
                 }
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
-                const int o = offs[2 * (s0 + u) + half];
+                const int k = 2 * (s0 + u) + half, kc = k / KK, kt = k - kc * KK;      // runtime here: unrolling all k-steps of the wide forms overflows the instruction cache
+                const int o = kc * PH * PWP + (kt / KW) * PWP + (kt % KW);
                 const float v0 = patch[o + rowoff0], v1 = patch[o + rowoff1];
 #pragma unroll
                 for (int m = 0; m < MTW; ++m) {
@@ -363,35 +415,129 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(const float* __restric
             }
         }
     }
-    // epilogue: out = relu?(acc + bias) + res1 + res2
-    const int ox = tx0 + j;
+    conv_mfma_epilogue<MTW>(acc, Wp, bias, res1, res2, out, b, Cout, Ho, Wo, ty0, tx0, wave, half, j, relu);
+}
+
+// Software-pipelined form of conv2d_mfma_kernel (3x3 stride 1, <= 2 M-tiles).  Both MFMA operands of a channel chunk
+// come from LDS (the input patch and that chunk's slice of the packed weights), so the MFMA loop waits on LDS only and
+// the global loads of chunk c + 1 -- issued before the loop of chunk c, written to the other LDS buffer after it -- stay
+// in flight behind the matrix pipe (vmcnt retires in order: a per-k-step weight load from global would drain them).
+// The per-thread staging descriptors (global offset, LDS offset, in-image mask) are chunk-independent and computed once.
+template <int KH, int KW, int S, int MTW>
+__global__ __launch_bounds__(256, MTW == 1 ? 3 : 2) void conv2d_mfma_pipe_kernel(const float* __restrict__ x, int64_t x_bs,
+                                                               const float* __restrict__ Wp, const float* __restrict__ bias,
+                                                               const float* __restrict__ res1, const float* __restrict__ res2,
+                                                               float* __restrict__ out, int Cin, int H, int W, int Cout,
+                                                               int Ho, int Wo, int pad, int relu, int tilesX, int KS) {
+    constexpr int KK = KH * KW;
+    constexpr int KC = CIB * KK;
+    constexpr int NS = KC / 2;                            // k-steps per chunk
+    constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW, PWP = PW + 1;
+    constexpr int PSZ = CIB * PH * PWP;
+    constexpr int TOT = CIB * PH * PW;
+    constexpr int NU = (TOT + 255) / 256;
+    constexpr int WSZ = NS * 64;                          // packed weight floats per chunk and M-tile
+    static_assert(WSZ % 256 == 0, "weight slice must split evenly over the workgroup");
+    constexpr int NWU = WSZ / 256;
+    __shared__ float patch[2][PSZ + 1];                   // [PSZ] = write-only slot of the threads past the patch
+    __shared__ float wsm[2][MTW][WSZ];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, j = lane & 31;
+    const int tile = blockIdx.x, b = blockIdx.y;
+    const int ty0 = (tile / tilesX) * TH, tx0 = (tile % tilesX) * TW;
+    const int iy0 = ty0 * S - pad, ix0 = tx0 * S - pad;
+    const float* xb = x + (int64_t)b * x_bs;
+    const int HW = H * W;
+    int goff[NU], lofc[NU];                                // lofc = LDS offset | channel-in-chunk << 20
+    float gm[NU];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int oy = ty0 + 2 * wave + t;
-        if (oy >= Ho || ox >= Wo) continue;
+    for (int u = 0; u < NU; ++u) {
+        const int i = u * 256 + threadIdx.x;
+        const int cc = i / (PH * PW), rem = i - cc * (PH * PW);
+        const int py = rem / PW, px = rem - py * PW;
+        const int iy = iy0 + py, ix = ix0 + px;
+        const bool in = i < TOT && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        goff[u] = in ? iy * W + ix : 0;
+        gm[u] = in ? 1.f : 0.f;
+        lofc[u] = (i < TOT ? cc * PH * PWP + py * PWP + px : PSZ) | (min(cc, CIB - 1) << 20);
+    }
+    f32x16 acc[MTW][2];
 #pragma unroll
-        for (int m = 0; m < MTW; ++m) {
-            float r1[16], r2[16], bv[16];
+    for (int m = 0; m < MTW; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int64_t idx = (((int64_t)b * Cout + co) * Ho + oy) * Wo + ox;
-                const bool ok = co < Cout;
-                bv[r] = (ok && bias) ? bias[co] : 0.f;
-                r1[r] = (ok && res1) ? res1[idx] : 0.f;
-                r2[r] = (ok && res2) ? res2[idx] : 0.f;
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+    const int64_t mts = (int64_t)KS * 64;
+    const int wtot = KS * 64;                              // packed floats per M-tile
+    const int rowoff0 = (2 * wave) * S * PWP + j * S, rowoff1 = rowoff0 + S * PWP;
+    float v[NU], wv[MTW][NWU];
+    // fetch only issues the loads -- as inline asm, because the compiler moves ordinary loads of read-only data down to
+    // their first use (behind the MFMAs); arrive() is the matching wait and carries every fetched register as an in/out
+    // operand so that no consumer can be scheduled ahead of it.
+    auto fetch = [&](int ci0) {                            // global -> registers for the chunk starting at channel ci0
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const float* p = xb + (int64_t)min(ci0 + (lofc[u] >> 20), Cin - 1) * HW + goff[u];
+            asm volatile("global_load_dword %0, %1, off" : "=v"(v[u]) : "v"(p));
+        }
+        const int wbase = ((ci0 * KK) >> 1) * 64;
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int u = 0; u < NWU; ++u) {
+                const float* p = Wp + m * mts + min(wbase + u * 256 + (int)threadIdx.x, wtot - 1);
+                asm volatile("global_load_dword %0, %1, off" : "=v"(wv[m][u]) : "v"(p));
             }
+    };
+    auto arrive = [&]() {
+        static_assert(NU == 11 && NWU == 9 && MTW <= 2, "operand lists below are written for the 3x3 stride-1 chunk");
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                       "+v"(v[9]), "+v"(v[10]));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (co < Cout) {
-                    float v = acc[m][t][r] + bv[r];
-                    if (relu) v = fmaxf(v, 0.f);
-                    out[(((int64_t)b * Cout + co) * Ho + oy) * Wo + ox] = v + r1[r] + r2[r];
-                }
+        for (int m = 0; m < MTW; ++m)
+            asm volatile("" : "+v"(wv[m][0]), "+v"(wv[m][1]), "+v"(wv[m][2]), "+v"(wv[m][3]), "+v"(wv[m][4]), "+v"(wv[m][5]),
+                              "+v"(wv[m][6]), "+v"(wv[m][7]), "+v"(wv[m][8]));
+    };
+    auto stash = [&](int bufi, int ci0) {
+        const int wbase = ((ci0 * KK) >> 1) * 64;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) patch[bufi][lofc[u] & 0xfffff] = v[u] * (ci0 + (lofc[u] >> 20) < Cin ? gm[u] : 0.f);
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int u = 0; u < NWU; ++u)   // k-steps past KS (Cin not a multiple of the chunk) are stored as zero
+                wsm[bufi][m][u * 256 + threadIdx.x] = wv[m][u] * (wbase + u * 256 + (int)threadIdx.x < wtot ? 1.f : 0.f);
+    };
+    fetch(0);
+    arrive();
+    stash(0, 0);
+    __syncthreads();
+    int buf = 0;
+    for (int ci0 = 0; ci0 < Cin; ci0 += CIB) {
+        // unconditional (the last pass re-reads clamped addresses and stashes into the unused buffer): under a uniform
+        // `if` the fetch and the stash become one block behind the MFMAs
+        fetch(ci0 + CIB);
+        __builtin_amdgcn_sched_barrier(0);
+        const float* pb = patch[buf];
+#pragma unroll      // fully unrolled: as a separate loop block the optimiser sinks the prefetch loads past it, next to their use
+        for (int s = 0; s < NS; ++s) {
+            const int o = half ? patch_off<KH, KW, PH, PWP>(2 * s + 1) : patch_off<KH, KW, PH, PWP>(2 * s);
+            const float v0 = pb[o + rowoff0], v1 = pb[o + rowoff1];
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                const float a = wsm[buf][m][s * 64 + lane];
+                acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v0, acc[m][0], 0, 0, 0);
+                acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v1, acc[m][1], 0, 0, 0);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        arrive();
+        stash(buf ^ 1, ci0 + CIB);
+        __syncthreads();
+        buf ^= 1;
     }
+    conv_mfma_epilogue<MTW>(acc, Wp, bias, res1, res2, out, b, Cout, Ho, Wo, ty0, tx0, wave, half, j, relu);
 }
 
 }  // namespace
@@ -449,7 +595,12 @@ extern "C" int bem_conv2d_mfma_f32(const float* x, int64_t x_bstride, const floa
 #define BEM_CONV_LAUNCH(KH_, KW_, S_, MTW_) \
     conv2d_mfma_kernel<KH_, KW_, S_, MTW_><<<grid, 256, 0, s>>>(x, x_bstride, Wp, bias, res1, res2, out, Cin, H, W, Cout, Ho, Wo, pad, relu, tilesX, KS)
     if (KH == 3 && KW == 3 && stride == 1) {
-        if (MT == 1) BEM_CONV_LAUNCH(3, 3, 1, 1);
+        static const bool pipe = !(getenv("BEM_CONV_PIPE") && getenv("BEM_CONV_PIPE")[0] == '0');
+        if (MT <= 2 && pipe) {
+            if (MT == 1) conv2d_mfma_pipe_kernel<3, 3, 1, 1><<<grid, 256, 0, s>>>(x, x_bstride, Wp, bias, res1, res2, out, Cin, H, W, Cout, Ho, Wo, pad, relu, tilesX, KS);
+            else conv2d_mfma_pipe_kernel<3, 3, 1, 2><<<grid, 256, 0, s>>>(x, x_bstride, Wp, bias, res1, res2, out, Cin, H, W, Cout, Ho, Wo, pad, relu, tilesX, KS);
+        }
+        else if (MT == 1) BEM_CONV_LAUNCH(3, 3, 1, 1);
         else if (MT == 2) BEM_CONV_LAUNCH(3, 3, 1, 2);
         else if (MT == 3) BEM_CONV_LAUNCH(3, 3, 1, 3);
         else BEM_CONV_LAUNCH(3, 3, 1, 5);

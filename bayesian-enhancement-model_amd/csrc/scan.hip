@@ -8,6 +8,7 @@
 // 6 steps), waves exchange their aggregates through LDS and a running carry links successive chunks.
 // The reverse directions use the mirrored lane / wave / element order of the same code.
 #include "bem_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -416,13 +417,15 @@ __global__ __launch_bounds__(NT) void ss2d_scan_kernel(
 // Whole-row form for L == NT * E (the 128x128 / 64x64 / 32x32 planes of a 256x256 image): x, the forward result and the
 // reverse result stay in registers, so x is read once and y written once; no bounds masks.  C_t is reloaded from the
 // (L2-resident) x_dbl plane after the scan instead of being held across it.
-template <int E>
+template <int E, int RT>      // RT = dt_rank when known at compile time (its plane loads then issue together), 0 = runtime R
 __device__ __forceinline__ void ss2d_coeffs_full(const float* __restrict__ xd, const float* __restrict__ wdt, float dtb,
-                                                 float Ak, const float (&x)[E], int t0, int L, int R, float (&a)[E],
+                                                 float Ak, const float (&x)[E], int t0, int L, int Rr, float (&a)[E],
                                                  float (&b)[E]) {
+    const int R = RT ? RT : Rr;
 #pragma unroll
     for (int e = 0; e < E; ++e) a[e] = dtb;
-    for (int r = 0; r < R; ++r) {
+#pragma unroll
+    for (int r = 0; r < (RT ? RT : R); ++r) {
         const float w = wdt[r];
 #pragma unroll
         for (int i = 0; i < E; i += 4) {
@@ -444,14 +447,15 @@ __device__ __forceinline__ void ss2d_coeffs_full(const float* __restrict__ xd, c
     }
 }
 
-template <int NT, int E>
+template <int NT, int E, int RT>
 __global__ __launch_bounds__(NT) void ss2d_scan_full_kernel(
     const float* __restrict__ x0, const float* __restrict__ x1, const float* __restrict__ xd0,
     const float* __restrict__ xd1, const float* __restrict__ dtw, const float* __restrict__ dtb,
     const float* __restrict__ A, const float* __restrict__ Ds, float* __restrict__ y0,
-    float* __restrict__ y1, int Bn, int C, int R) {
+    float* __restrict__ y1, int Bn, int C, int Rr) {
     __shared__ float agg[2 * (NT / BEM_WAVE)];
     constexpr int L = NT * E;
+    const int R = RT ? RT : Rr;
     const int total = gridDim.x, lin = blockIdx.x;      // XCD-aware order, as in ss2d_scan_kernel
     const int per = total / 8, rem = total % 8, xcd = lin % 8, idx = lin / 8;
     const int wi = xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
@@ -469,7 +473,7 @@ __global__ __launch_bounds__(NT) void ss2d_scan_full_kernel(
     }
     {
         float a[E], bb[E];
-        ss2d_coeffs_full<E>(xd, dtw + ((int64_t)kf * C + c) * R, dtb[kf * C + c], A[kf * C + c], x, t0, L, R, a, bb);
+        ss2d_coeffs_full<E, RT>(xd, dtw + ((int64_t)kf * C + c) * R, dtb[kf * C + c], A[kf * C + c], x, t0, L, R, a, bb);
         float carry = 0.f;
         float hh = block_scan_enter<NT, E, false>(a, bb, carry, agg);
         const float Df = Ds[kf * C + c];
@@ -488,7 +492,7 @@ __global__ __launch_bounds__(NT) void ss2d_scan_full_kernel(
     {
         float a[E], bb[E];
         const float* xdr = xd + (int64_t)(R + 2) * L;
-        ss2d_coeffs_full<E>(xdr, dtw + ((int64_t)kr * C + c) * R, dtb[kr * C + c], A[kr * C + c], x, t0, L, R, a, bb);
+        ss2d_coeffs_full<E, RT>(xdr, dtw + ((int64_t)kr * C + c) * R, dtb[kr * C + c], A[kr * C + c], x, t0, L, R, a, bb);
         float carry = 0.f;
         float hh = block_scan_enter<NT, E, true>(a, bb, carry, agg);
         const float Dr = Ds[kr * C + c];
@@ -507,6 +511,263 @@ __global__ __launch_bounds__(NT) void ss2d_scan_full_kernel(
 #pragma unroll
     for (int i = 0; i < E; i += 4)
         *reinterpret_cast<float4*>(yr + t0 + i) = make_float4(y[i], y[i + 1], y[i + 2], y[i + 3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Channel-blocked whole-row form, L == NT * 4 * T.  The per-channel kernels above re-read the 2 (R + 2) x_dbl planes
+// of an image from L2 once per channel (C times), which makes them L2-bandwidth bound; here a workgroup owns CB
+// channels of one (orientation, image) and every thread keeps the float4 of each x_dbl plane it needs in registers
+// while it walks the CB channels.  Lane l of a tile owns 4 consecutive positions, so a wavefront load is one
+// contiguous 1 KB segment; the wavefront scan runs on DPP row shifts / row broadcasts (no LDS traffic); y of both
+// directions accumulates in registers (x read twice, y written once).
+// ------------------------------------------------------------------------------------------------
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_mov(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                                 CTRL, ROWMASK, 0xf, false));
+}
+__device__ __forceinline__ float lane_bcast(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+#define BEM_SCAN_STEP(CTRL, RM)                                         \
+    {                                                                   \
+        const float Pp = dpp_mov<CTRL, RM>(1.f, P), Sp = dpp_mov<CTRL, RM>(0.f, S); \
+        S = fmaf(P, Sp, S);                                             \
+        P = P * Pp;                                                     \
+    }
+// inclusive scan of the per-lane affine maps (P, S) in ascending (REV = false) / descending (REV = true) lane order;
+// returns the exclusive map (Pe, Se) of every lane and leaves the wavefront total in lane 63 (0 for REV).
+template <bool REV>
+__device__ __forceinline__ void wave_scan_affine(float& P, float& S, float& Pe, float& Se) {
+    if (!REV) {
+        BEM_SCAN_STEP(0x111, 0xf) BEM_SCAN_STEP(0x112, 0xf) BEM_SCAN_STEP(0x114, 0xf) BEM_SCAN_STEP(0x118, 0xf)   // row_shr 1,2,4,8
+        BEM_SCAN_STEP(0x142, 0xa) BEM_SCAN_STEP(0x143, 0xc)                                                       // row_bcast 15 / 31
+        Pe = dpp_mov<0x138, 0xf>(1.f, P);   // wave_shr 1
+        Se = dpp_mov<0x138, 0xf>(0.f, S);
+    } else {
+        BEM_SCAN_STEP(0x101, 0xf) BEM_SCAN_STEP(0x102, 0xf) BEM_SCAN_STEP(0x104, 0xf) BEM_SCAN_STEP(0x108, 0xf)   // row_shl 1,2,4,8
+        const int lane = threadIdx.x & 63;
+        {   // rows 0 / 2 append the suffix of rows 1 / 3 (their lane 16 / 48)
+            const float P16 = lane_bcast(P, 16), S16 = lane_bcast(S, 16), P48 = lane_bcast(P, 48), S48 = lane_bcast(S, 48);
+            const bool take = (lane & 16) == 0;
+            const float Pp = take ? ((lane & 32) ? P48 : P16) : 1.f, Sp = take ? ((lane & 32) ? S48 : S16) : 0.f;
+            S = fmaf(P, Sp, S);
+            P = P * Pp;
+        }
+        {   // rows 0, 1 append the suffix of rows 2, 3 (lane 32)
+            const float P32 = lane_bcast(P, 32), S32 = lane_bcast(S, 32);
+            const bool take = lane < 32;
+            const float Pp = take ? P32 : 1.f, Sp = take ? S32 : 0.f;
+            S = fmaf(P, Sp, S);
+            P = P * Pp;
+        }
+        Pe = dpp_mov<0x130, 0xf>(1.f, P);   // wave_shl 1
+        Se = dpp_mov<0x130, 0xf>(0.f, S);
+    }
+}
+#undef BEM_SCAN_STEP
+
+template <int NT, int T, int CB, int R, int MINW>
+__global__ __launch_bounds__(NT, MINW) void ss2d_scan_rows_kernel(
+    // x / x_dbl deliberately not __restrict__: their loads must stay behind the barrier of the channel step they belong
+    // to (as invariant loads the compiler hoists all CB * T * 2 steps' loads to the top and runs out of registers)
+    const float* x0, const float* x1, const float* xd0, const float* xd1, const float* __restrict__ dtw,
+    const float* __restrict__ dtb, const float* __restrict__ A, const float* __restrict__ Ds, float* y0, float* y1,
+    int Bn, int C) {
+    constexpr int NW = NT / BEM_WAVE, L = NT * 4 * T;
+    constexpr int NSLOT = CB > 1 ? CB : 2;
+    __shared__ float agg[NSLOT][2 * NW];
+    const int G = (C + CB - 1) / CB;
+    const int total = gridDim.x, lin = blockIdx.x;      // XCD-aware order: the channel groups of one (o, b) share an L2
+    const int per = total / 8, rem = total % 8, xcd = lin % 8, idx = lin / 8;
+    const int wi = xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
+    const int g = wi % G, b = (wi / G) % Bn, o = wi / (G * Bn);
+    const float* xb = (o ? x1 : x0) + (int64_t)b * C * L;
+    const float* xdb = (o ? xd1 : xd0) + (int64_t)b * 2 * (R + 2) * L;
+    float* yb = (o ? y1 : y0) + (int64_t)b * C * L;
+    const int lane = threadIdx.x & (BEM_WAVE - 1), wave = threadIdx.x / BEM_WAVE;
+    float4 y[CB][T];
+    int slot = 0;
+#pragma unroll
+    for (int dir = 0; dir < 2; ++dir) {
+        const float* xd = xdb + (int64_t)dir * (R + 2) * L;
+        const int kd = o + 2 * dir;
+        float carry[CB];
+#pragma unroll
+        for (int ch = 0; ch < CB; ++ch) carry[ch] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < T; ++kk) {
+            const int k = dir ? T - 1 - kk : kk;
+            const int pos = (k * NT + threadIdx.x) * 4;
+            __builtin_amdgcn_sched_barrier(0);      // keep the scheduler from pulling every later step's loads up here
+            float4 dq[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) dq[r] = *reinterpret_cast<const float4*>(xd + (int64_t)r * L + pos);
+            const float4 Bq = *reinterpret_cast<const float4*>(xd + (int64_t)R * L + pos);
+            const float4 Cq = *reinterpret_cast<const float4*>(xd + (int64_t)(R + 1) * L + pos);
+            const float Bv[4] = {Bq.x, Bq.y, Bq.z, Bq.w}, Cv[4] = {Cq.x, Cq.y, Cq.z, Cq.w};
+#pragma unroll
+            for (int ch = 0; ch < CB; ++ch) {
+                const int c = min(g * CB + ch, C - 1);          // a partial last group recomputes channel C - 1 (not stored)
+                __builtin_amdgcn_sched_barrier(0);
+                const float4 xq = *reinterpret_cast<const float4*>(xb + (int64_t)c * L + pos);
+                const float xv[4] = {xq.x, xq.y, xq.z, xq.w};
+                const float* wd = dtw + ((int64_t)kd * C + c) * R;
+                const float bias = dtb[kd * C + c], Ak = A[kd * C + c], Dk = Ds[kd * C + c];
+                float a[4], bb[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = bias;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float w = wd[r];
+                    a[0] = fmaf(w, dq[r].x, a[0]); a[1] = fmaf(w, dq[r].y, a[1]);
+                    a[2] = fmaf(w, dq[r].z, a[2]); a[3] = fmaf(w, dq[r].w, a[3]);
+                }
+                float P = 1.f, S = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = dir ? 3 - i : i;
+                    const float dl = bem_softplus(a[e]);
+                    a[e] = bem_fexp(dl * Ak);
+                    bb[e] = dl * Bv[e] * xv[e];
+                    S = fmaf(a[e], S, bb[e]);
+                    P = P * a[e];
+                }
+                float Pe, Se;
+                if (dir) wave_scan_affine<true>(P, S, Pe, Se);
+                else wave_scan_affine<false>(P, S, Pe, Se);
+                float hw = carry[ch];
+                if (NW > 1) {
+                    float* ag = agg[slot];
+                    if (lane == (dir ? 0 : BEM_WAVE - 1)) { ag[2 * wave] = P; ag[2 * wave + 1] = S; }
+                    __syncthreads();
+                    float hend = hw;
+                    const int rw = dir ? NW - 1 - wave : wave;
+#pragma unroll
+                    for (int i = 0; i < NW; ++i) {
+                        const int w = dir ? NW - 1 - i : i;
+                        const float Pw = ag[2 * w], Sw = ag[2 * w + 1];
+                        hend = fmaf(Pw, hend, Sw);
+                        if (i < rw) hw = fmaf(Pw, hw, Sw);
+                    }
+                    carry[ch] = hend;
+                    // the slot is rewritten NSLOT channel steps later; the barriers of the steps in between order that
+                    // write after every read above
+                    slot = (slot + 1 == NSLOT) ? 0 : slot + 1;
+                } else {
+                    const float Pt = lane_bcast(P, dir ? 0 : BEM_WAVE - 1), St = lane_bcast(S, dir ? 0 : BEM_WAVE - 1);
+                    carry[ch] = fmaf(Pt, hw, St);
+                }
+                float hh = fmaf(Pe, hw, Se);
+                float yv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = dir ? 3 - i : i;
+                    hh = fmaf(a[e], hh, bb[e]);
+                    yv[e] = fmaf(Cv[e], hh, Dk * xv[e]);
+                }
+                if (dir == 0) y[ch][k] = make_float4(yv[0], yv[1], yv[2], yv[3]);
+                else { y[ch][k].x += yv[0]; y[ch][k].y += yv[1]; y[ch][k].z += yv[2]; y[ch][k].w += yv[3]; }
+                // pin the result here: otherwise the optimiser sinks every step's replay down to the final stores and keeps
+                // each step's coefficients alive until then (~50 registers per tile)
+                asm volatile("" : "+v"(y[ch][k].x), "+v"(y[ch][k].y), "+v"(y[ch][k].z), "+v"(y[ch][k].w));
+            }
+        }
+    }
+#pragma unroll
+    for (int ch = 0; ch < CB; ++ch) {
+        const int c = g * CB + ch;
+        if (c < C) {
+#pragma unroll
+            for (int k = 0; k < T; ++k) *reinterpret_cast<float4*>(yb + (int64_t)c * L + (k * NT + threadIdx.x) * 4) = y[ch][k];
+        }
+    }
+}
+
+// Chunked form without bounds masks for L % (NT * E) == 0 (L = 16384: 8 chunks of 2048): same chunk / carry structure as
+// ss2d_scan_kernel, every load unconditional so the loads of a chunk issue back to back.
+template <int NT, int E, int RT>
+__global__ __launch_bounds__(NT) void ss2d_scan_chunks_kernel(
+    const float* __restrict__ x0, const float* __restrict__ x1, const float* __restrict__ xd0,
+    const float* __restrict__ xd1, const float* __restrict__ dtw, const float* __restrict__ dtb,
+    const float* __restrict__ A, const float* __restrict__ Ds, float* __restrict__ y0,
+    float* __restrict__ y1, int Bn, int C, int L, int Rr) {
+    __shared__ float agg[2 * (NT / BEM_WAVE)];
+    constexpr int CH = NT * E;
+    const int R = RT ? RT : Rr;
+    const int total = gridDim.x, lin = blockIdx.x;      // XCD-aware order, as in ss2d_scan_kernel
+    const int per = total / 8, rem = total % 8, xcd = lin % 8, idx = lin / 8;
+    const int wi = xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
+    const int c = wi % C, b = (wi / C) % Bn, o = wi / (C * Bn);
+    const float* xr = (o ? x1 : x0) + ((int64_t)b * C + c) * L;
+    const float* xd = (o ? xd1 : xd0) + (int64_t)b * 2 * (R + 2) * L;
+    const float* xdr = xd + (int64_t)(R + 2) * L;
+    float* yr = (o ? y1 : y0) + ((int64_t)b * C + c) * L;
+    const int kf = o, kr = o + 2;
+    const float* wf = dtw + ((int64_t)kf * C + c) * R;
+    const float* wr = dtw + ((int64_t)kr * C + c) * R;
+    const float bf = dtb[kf * C + c], br = dtb[kr * C + c];
+    const float Af = A[kf * C + c], Ar = A[kr * C + c];
+    const float Df = Ds[kf * C + c], Dr = Ds[kr * C + c];
+    const int nchunks = L / CH;
+    float carry = 0.f;
+    for (int j = 0; j < nchunks; ++j) {
+        const int t0 = j * CH + threadIdx.x * E;
+        float x[E], a[E], bb[E], y[E];
+#pragma unroll
+        for (int i = 0; i < E; i += 4) {
+            const float4 q = *reinterpret_cast<const float4*>(xr + t0 + i);
+            x[i] = q.x; x[i + 1] = q.y; x[i + 2] = q.z; x[i + 3] = q.w;
+        }
+        float4 cq[E / 4];
+#pragma unroll
+        for (int i = 0; i < E; i += 4) cq[i / 4] = *reinterpret_cast<const float4*>(xd + (int64_t)(R + 1) * L + t0 + i);
+        ss2d_coeffs_full<E, RT>(xd, wf, bf, Af, x, t0, L, R, a, bb);
+        float hh = block_scan_enter<NT, E, false>(a, bb, carry, agg);
+#pragma unroll
+        for (int i = 0; i < E; i += 4) {
+            const float cv[4] = {cq[i / 4].x, cq[i / 4].y, cq[i / 4].z, cq[i / 4].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                hh = a[i + k] * hh + bb[i + k];
+                y[i + k] = fmaf(cv[k], hh, Df * x[i + k]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < E; i += 4)
+            *reinterpret_cast<float4*>(yr + t0 + i) = make_float4(y[i], y[i + 1], y[i + 2], y[i + 3]);
+    }
+    carry = 0.f;
+    for (int j = nchunks - 1; j >= 0; --j) {
+        const int t0 = j * CH + threadIdx.x * E;
+        float x[E], a[E], bb[E], y[E];
+#pragma unroll
+        for (int i = 0; i < E; i += 4) {
+            const float4 q = *reinterpret_cast<const float4*>(xr + t0 + i);
+            x[i] = q.x; x[i + 1] = q.y; x[i + 2] = q.z; x[i + 3] = q.w;
+        }
+        float4 cq[E / 4], yq[E / 4];
+#pragma unroll
+        for (int i = 0; i < E; i += 4) {
+            cq[i / 4] = *reinterpret_cast<const float4*>(xdr + (int64_t)(R + 1) * L + t0 + i);
+            yq[i / 4] = *reinterpret_cast<const float4*>(yr + t0 + i);       // this thread's own earlier stores
+        }
+        ss2d_coeffs_full<E, RT>(xdr, wr, br, Ar, x, t0, L, R, a, bb);
+        float hh = block_scan_enter<NT, E, true>(a, bb, carry, agg);
+#pragma unroll
+        for (int i = E - 4; i >= 0; i -= 4) {
+            const float cv[4] = {cq[i / 4].x, cq[i / 4].y, cq[i / 4].z, cq[i / 4].w};
+            const float yv[4] = {yq[i / 4].x, yq[i / 4].y, yq[i / 4].z, yq[i / 4].w};
+#pragma unroll
+            for (int k = 3; k >= 0; --k) {
+                hh = a[i + k] * hh + bb[i + k];
+                y[i + k] = yv[k] + fmaf(cv[k], hh, Dr * x[i + k]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < E; i += 4)
+            *reinterpret_cast<float4*>(yr + t0 + i) = make_float4(y[i], y[i + 1], y[i + 2], y[i + 3]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -574,18 +835,41 @@ extern "C" int bem_ss2d_scan_f32(const float* x0, const float* x1, const float* 
     hipStream_t s = (hipStream_t)stream;
     const int grid = C * B * 2;
 #define BEM_SS2D(NT, E) ss2d_scan_kernel<NT, E><<<grid, NT, 0, s>>>(x0, x1, xd0, xd1, dtw, dtb, A, Ds, y0, y1, B, C, L, R)
-#define BEM_SS2D_FULL(NT, E) ss2d_scan_full_kernel<NT, E><<<grid, NT, 0, s>>>(x0, x1, xd0, xd1, dtw, dtb, A, Ds, y0, y1, B, C, R)
+#define BEM_SS2D_FULL_R(NT, E, RT) ss2d_scan_full_kernel<NT, E, RT><<<grid, NT, 0, s>>>(x0, x1, xd0, xd1, dtw, dtb, A, Ds, y0, y1, B, C, R)
+#define BEM_SS2D_FULL(NT, E) BEM_SS2D_FULL_R(NT, E, 0)      // runtime dt_rank: unrolling its plane loads measured slower (register pressure)
+#define BEM_SS2D_CHUNKS(RT) ss2d_scan_chunks_kernel<256, 8, RT><<<grid, 256, 0, s>>>(x0, x1, xd0, xd1, dtw, dtb, A, Ds, y0, y1, B, C, L, R)
     const bool al = (((uintptr_t)x0 | (uintptr_t)x1 | (uintptr_t)xd0 | (uintptr_t)xd1 | (uintptr_t)y0 | (uintptr_t)y1) & 15) == 0;
+    // channel-blocked whole-row forms for the plane sizes and dt_ranks of a 256x256 image (n_feat 40: C = 40 / 80 / 160)
+    static const int variant = getenv("BEM_SCAN_VARIANT") ? atoi(getenv("BEM_SCAN_VARIANT")) : 1;
+#define BEM_SS2D_ROWS(NT, T, CB, RT, MW) do { ss2d_scan_rows_kernel<NT, T, CB, RT, MW><<<((C + CB - 1) / CB) * B * 2, NT, 0, s>>>( \
+        x0, x1, xd0, xd1, dtw, dtb, A, Ds, y0, y1, B, C); return bem_check_launch("ss2d_scan"); } while (0)
+    if (al && variant) {
+        if (L == 1024 && R == 10) { if (variant == 2) BEM_SS2D_ROWS(256, 1, 2, 10, 6); else if (variant == 3) BEM_SS2D_ROWS(256, 1, 4, 10, 4); else BEM_SS2D_ROWS(256, 1, 4, 10, 5); }
+        if (L == 4096 && R == 5) {
+            if (variant == 2) BEM_SS2D_ROWS(512, 2, 4, 5, 4); else if (variant == 3) BEM_SS2D_ROWS(256, 4, 2, 5, 5);
+            else if (variant == 4) BEM_SS2D_ROWS(1024, 1, 4, 5, 4); else BEM_SS2D_ROWS(256, 4, 4, 5, 4);
+        }
+        if (L == 16384 && R == 3) {
+            if (variant == 2) BEM_SS2D_ROWS(1024, 4, 4, 3, 4); else if (variant == 3) BEM_SS2D_ROWS(512, 8, 2, 3, 4);
+            else if (variant == 4) BEM_SS2D_ROWS(1024, 4, 1, 3, 4); else BEM_SS2D_ROWS(1024, 4, 2, 3, 4);
+        }
+    }
+#undef BEM_SS2D_ROWS
     // whole-row forms: x read once, y written once.  (A 1024 x 16 form for L = 16384 measured slower than the chunked
     // kernel -- 128-VGPR budget, 2 workgroups per CU -- so rows longer than 4096 stay on the chunked path.)
     if (al && L == 4096) BEM_SS2D_FULL(512, 8);
     else if (al && L == 1024) BEM_SS2D_FULL(128, 8);
     else if (al && L == 256) BEM_SS2D_FULL(64, 4);
+    else if (al && L > 2048 && L % 2048 == 0) {
+        if (R == 3) BEM_SS2D_CHUNKS(3); else BEM_SS2D_CHUNKS(0);
+    }
     else if (L <= 256) BEM_SS2D(64, 4);
     else if (L <= 1024) BEM_SS2D(128, 8);
     else BEM_SS2D(256, 8);
 #undef BEM_SS2D
 #undef BEM_SS2D_FULL
+#undef BEM_SS2D_FULL_R
+#undef BEM_SS2D_CHUNKS
     return bem_check_launch("ss2d_scan");
 }
 

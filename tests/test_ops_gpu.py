@@ -105,7 +105,9 @@ def _ss2d_case(B, C, H, W, seed):
     return sd, x, R
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 4, 4), (1, 40, 16, 12), (2, 16, 7, 10), (1, 24, 64, 48), (1, 8, 33, 70)])
+@pytest.mark.parametrize("shape", [(2, 8, 4, 4), (1, 40, 16, 12), (2, 16, 7, 10), (1, 24, 64, 48), (1, 8, 33, 70),
+                                   # whole-row forms (L = 256 / 1024 / 4096; dt_rank 3, 5, 10, other) and the mask-free chunked form (L % 2048 == 0)
+                                   (2, 40, 16, 16), (1, 80, 32, 32), (1, 160, 16, 16), (1, 8, 64, 64), (1, 40, 64, 96), (1, 8, 128, 128), (1, 80, 32, 128)])
 def test_ss2d_scan_vs_oracle(ops, shape):
     """transpose -> x_proj GEMMs -> bem_ss2d_scan -> transpose back, against cross_scan/x_proj/dt_proj/
     selective_scan/cross_merge of the oracle (pre out_norm).  Tolerance 2e-4 rel / 2e-5 abs."""
