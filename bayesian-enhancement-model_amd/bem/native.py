@@ -75,6 +75,7 @@ SIGNATURES = {
     "bem_space_to_depth_f32": [P, P, I, I, I, I, P],
     "bem_pixel_shuffle2_f32": [P, P, I, I, I, I, P],
     "bem_bnn_sample_f32": [P, P, P, P, I, I64, U64, U64, P],
+    "bem_select_best_f32": [P, P, P, P, P, I, I, I64, P],
     "bem_pad_reflect_f32": [P, P, I, I, I, I, I, P],
     "bem_resize_down_f32": [P, P, I, I, I, I, P],
     "bem_randn_f32": [P, I64, U64, U64, P],

@@ -540,6 +540,21 @@ def candidate_finalize(pred, target, samples_per_image, h, w, gt_mean):
     return fin, ps
 
 
+def select_best(final, psnr, samples_per_image):
+    """eval.py:284-285 on the device: (best (B) int32, best_psnr (B), best_images (B,3,h,w)); row = image*N + sample."""
+    _chk(final, "final"); _chk(psnr, "psnr")
+    Bn = final.shape[0]
+    N = samples_per_image
+    if Bn % N or psnr.numel() != Bn:
+        raise ValueError("select_best: shapes")
+    B = Bn // N
+    best = torch.empty(B, device=final.device, dtype=torch.int32)
+    bp = torch.empty(B, device=final.device, dtype=torch.float32)
+    img = torch.empty((B,) + tuple(final.shape[1:]), device=final.device, dtype=final.dtype)
+    check(lib().bem_select_best_f32(_p(final), _p(psnr), _p(best), _p(bp), _p(img), B, N, final[0].numel(), _stream()), "select_best")
+    return best, bp, img
+
+
 # --------------------------------------------------------------------------- launch timing ----
 # bench.py asks for ONE op's launches to be bracketed by HIP events on the launch stream (torch's
 # current stream is the stream every wrapper launches on), together with that launch's algorithmic

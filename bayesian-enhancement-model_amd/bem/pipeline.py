@@ -64,13 +64,19 @@ class BEMPipeline:
         return rel.index(max(rel))
 
     @torch.no_grad()
-    def enhance(self, imgs, targets, num_samples, gt_mean=True, deterministic=False, **kw):
+    def enhance(self, imgs, targets, num_samples, gt_mean=True, deterministic=False, sync=True, **kw):
+        """candidates + per-image selection.  The selection (first maximum of psnr / max(psnr), eval.py:284-285) runs on the
+        device; with ``sync=False`` nothing is copied to the host, ``best`` / ``best_psnr`` stay device tensors and the
+        caller may enqueue the next batch at once (bench.py does)."""
         r = self.candidates(imgs, targets, num_samples, gt_mean, deterministic, **kw)
-        B, N = imgs.shape[0], r["N"]
-        ps = r["psnr"].view(B, N).cpu().tolist()
-        best = [self.select(row) if targets is not None else 0 for row in ps]
-        idx = torch.tensor([i * N + b for i, b in enumerate(best)], device=imgs.device)
-        r.update(best=best, best_images=r["final"].index_select(0, idx), best_psnr=[ps[i][b] for i, b in enumerate(best)])
+        N = r["N"]
+        best, bp, img = ops.select_best(r["final"], r["psnr"], N)
+        if targets is None:
+            best = torch.zeros_like(best)          # no reference: the reference keeps the first sample
+            img = r["final"][::N].contiguous()
+        r.update(best=best, best_images=img, best_psnr=bp)
+        if sync:
+            r["best"], r["best_psnr"] = best.cpu().tolist(), bp.cpu().tolist()
         return r
 
 

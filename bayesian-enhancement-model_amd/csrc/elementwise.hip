@@ -1,6 +1,7 @@
 // Bandwidth-bound helpers: quaternion/Haar primitives, channel-attention statistics + weight folding,
 // layout shuffles, bilinear resampling, Bayesian weight sampling, Monte-Carlo loop reductions.
 #include "bem_common.h"
+#include <algorithm>
 
 thread_local char bem_err_buf[512] = "";
 extern "C" const char* bem_last_error(void) { return bem_err_buf; }
@@ -555,6 +556,38 @@ __global__ void cand_psnr_kernel(const double* __restrict__ ws, float* __restric
     psnr[bn] = has_target ? (m == 0 ? 100.f : (float)(10.0 * log10(1.0 / m))) : 0.f;
 }
 
+// eval.py:284-285 with psnr_weight = 1: scores = psnr / max(psnr) per image, best = first index of the maximum score
+// (python list.index(max(...)) semantics, evaluated in f64 like the reference's python floats).  One thread per image.
+__global__ void select_best_kernel(const float* __restrict__ psnr, int* __restrict__ best, float* __restrict__ best_psnr, int B, int N) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* p = psnr + (int64_t)b * N;
+    double m = (double)p[0];
+    for (int i = 1; i < N; ++i) m = fmax(m, (double)p[i]);
+    int bi = 0;
+    double bs = (double)p[0] / m;
+    for (int i = 1; i < N; ++i) {
+        const double sc = (double)p[i] / m;
+        if (sc > bs) { bs = sc; bi = i; }
+    }
+    best[b] = bi;
+    best_psnr[b] = p[bi];
+}
+
+__global__ void gather_best_kernel(const float* __restrict__ cand, const int* __restrict__ best, float* __restrict__ out, int N, int64_t chw4) {
+    const int b = blockIdx.y;
+    const float4* src = reinterpret_cast<const float4*>(cand) + ((int64_t)b * N + best[b]) * chw4;
+    float4* dst = reinterpret_cast<float4*>(out) + (int64_t)b * chw4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < chw4; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+__global__ void gather_best_scalar_kernel(const float* __restrict__ cand, const int* __restrict__ best, float* __restrict__ out, int N, int64_t chw) {
+    const int b = blockIdx.y;
+    const float* src = cand + ((int64_t)b * N + best[b]) * chw;
+    float* dst = out + (int64_t)b * chw;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < chw; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 }  // namespace
 
 // ================================================================ C ABI =========================
@@ -749,4 +782,22 @@ extern "C" int bem_randn_f32(float* out, int64_t n, uint64_t seed, uint64_t stre
     if (n == 0) return BEM_OK;
     randn_kernel<<<GRID1D(n), 256, 0, (hipStream_t)stream>>>(out, n, seed, stream_id);
     return bem_check_launch("randn");
+}
+
+extern "C" int bem_select_best_f32(const float* cand, const float* psnr, int* best, float* best_psnr, float* best_img, int B, int N,
+                                   int64_t chw, void* stream) {
+    BEM_REQUIRE(psnr && best && best_psnr, "select_best: null tensor");
+    BEM_REQUIRE(B >= 0 && B <= 65535 && N >= 1 && chw >= 0, "select_best: bad shape B=%d N=%d", B, N);
+    BEM_REQUIRE((cand == nullptr) == (best_img == nullptr), "select_best: cand and best_img go together");
+    if (B == 0) return BEM_OK;
+    hipStream_t s = (hipStream_t)stream;
+    select_best_kernel<<<cdiv(B, 64), 64, 0, s>>>(psnr, best, best_psnr, B, N);
+    if (cand && chw > 0) {
+        const bool v4 = chw % 4 == 0 && (((uintptr_t)cand | (uintptr_t)best_img) & 15) == 0;
+        const int64_t n = v4 ? chw / 4 : chw;
+        dim3 grid((unsigned)std::min<int64_t>(cdiv64(n, 256), 1024), B);
+        if (v4) gather_best_kernel<<<grid, 256, 0, s>>>(cand, best, best_img, N, n);
+        else gather_best_scalar_kernel<<<grid, 256, 0, s>>>(cand, best, best_img, N, n);
+    }
+    return bem_check_launch("select_best");
 }

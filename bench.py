@@ -83,7 +83,7 @@ def main():
     lq, gt = synthetic_pair((B, 3, S, S), seed=287128 + rank, device=dev)     # every rank its own images
 
     def step(i):
-        r = pipe.enhance(lq, gt, N, gt_mean=True, seed=1000 + i)
+        r = pipe.enhance(lq, gt, N, gt_mean=True, seed=1000 + i, sync=False)   # selection on the device, no host sync per step
         if world > 1:
             return gather_candidates(r["final"], r["psnr"], world)
         return r["final"], r["psnr"]

@@ -219,6 +219,12 @@ int bem_candidate_finalize_f32(const float* pred, const float* target, float* fi
                                int Bn, int samples_per_image, int Hp, int Wp, int h, int w, int gt_mean,
                                void* stream);   /* ws: scratch of 7*Bn doubles (zeroed by the call) */
 
+/* Candidate selection of eval.py:284-285 (psnr_weight = 1): per image, score_i = psnr_i / max_j psnr_j, best = FIRST index
+ * of the maximum score (python list.index(max(...))); best (B) int32, best_psnr (B), and -- when cand/best_img are given --
+ * best_img[b] = cand[b*N + best[b]] (chw floats each).  Everything stays on the device: no host round trip per step. */
+int bem_select_best_f32(const float* cand, const float* psnr, int* best, float* best_psnr, float* best_img, int B, int N,
+                        int64_t chw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -439,3 +439,20 @@ def test_image_prep_kernels(ops):
     d = dev(torch.ones(2, 4, 5, 6)); sc = torch.rand(2, 6, 5, 6, generator=g)
     ops.add_channels(dev(sc), d, 0, src_c0=3, C=3)
     close(d[:, :3], 1 + sc[:, 3:6], 0, 1e-7, "add_channels"); assert (d[:, 3] == 1).all()
+
+
+def test_select_best_first_max(ops):
+    """bem_select_best vs BEMPipeline.select (eval.py:284-285): ties -> first index, negative PSNRs divide by a negative max."""
+    from bem.pipeline import BEMPipeline
+    rows = [[20.0, 25.5, 25.5, 3.0], [7.0, 7.0, 7.0, 7.0], [-3.0, -1.0, -2.0, -1.0], [100.0, 99.0, 100.0, 1.0], [1.5, 2.5, 3.5, 4.5]]
+    ps = dev(torch.tensor(rows).reshape(-1))
+    g = torch.Generator().manual_seed(5)
+    fin = dev(torch.rand(len(rows) * 4, 3, 6, 5, generator=g))
+    best, bp, img = ops.select_best(fin, ps, 4)
+    exp = [BEMPipeline.select(r) for r in rows]
+    assert best.cpu().tolist() == exp
+    assert bp.cpu().tolist() == [pytest.approx(r[e]) for r, e in zip(rows, exp)]
+    assert torch.equal(img.cpu(), torch.stack([fin[i * 4 + e].cpu() for i, e in enumerate(exp)]))
+    fin2 = dev(torch.rand(4, 3, 3, 3, generator=g))                      # chw not a multiple of 4 -> scalar gather
+    b2, _, img2 = ops.select_best(fin2, dev(torch.tensor([1.0, 5.0, 2.0, 9.0])), 2)
+    assert b2.cpu().tolist() == [1, 1] and torch.equal(img2.cpu(), fin2[[1, 3]].cpu())
