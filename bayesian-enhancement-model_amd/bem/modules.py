@@ -303,14 +303,14 @@ class gdMlp(nn.Module):
             def prep():
                 return (ops.pack_pw_weight_gate(pi.weight.detach().reshape(2 * Hd, -1).contiguous(), Hd), pi.bias.detach().contiguous(),
                         dw.weight.detach().reshape(2 * Hd, 9).contiguous(), None if dw.bias is None else dw.bias.detach().contiguous(),
-                        ops.pack_pw_weight(po.weight.detach().reshape(po.out_channels, Hd).contiguous()),
+                        ops.pack_pw_weight(po.weight.detach().reshape(po.out_channels, Hd).contiguous(), x6=False),
                         None if po.bias is None else po.bias.detach().contiguous())
             return self._cache.get("fused", [pi.weight, pi.bias, dw.weight, po.weight], prep)
         w, b, ns = pi._sampled(B)
         Wpi = ops.pack_pw_weight_gate(w.reshape(ns, 2 * Hd, -1).contiguous(), Hd)
         w2, b2, _ = dw._sampled(B)
         w3, b3, _ = po._sampled(B)
-        Wpo = ops.pack_pw_weight(w3.reshape(ns, po.out_channels, Hd).contiguous())
+        Wpo = ops.pack_pw_weight(w3.reshape(ns, po.out_channels, Hd).contiguous(), x6=False)
         return Wpi, b.contiguous(), w2.reshape(ns, 2 * Hd * 9).contiguous(), (None if b2 is None else b2.contiguous()), Wpo, \
             (None if b3 is None else b3.contiguous())
 

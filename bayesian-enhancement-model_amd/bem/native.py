@@ -56,6 +56,9 @@ SIGNATURES = {
     "bem_pw_gemm_f32": [ctypes.POINTER(PwArgs), P],
     "bem_pack_pw_weight_f32": [P, P, I, I, I, P],
     "bem_pw_packed_elems": [I, I],
+    "bem_pw_gemm_x6_f32": [ctypes.POINTER(PwArgs), P],
+    "bem_pack_pw_weight_x6": [P, P, I, I, I, P],
+    "bem_pw_x6_packed_elems": [I, I],
     "bem_gdmlp_fused_f32": [ctypes.POINTER(GdmlpArgs), P],
     "bem_pack_pw_weight_gate_f32": [P, P, I, I, I, P],
     "bem_dwconv3x3_f32": [P, P, I64, P, I64, P, I, I, I, I, I, P],
@@ -85,7 +88,7 @@ SIGNATURES = {
     "bem_last_error": [],
     "bem_abi_version": [],
 }
-_RESTYPE = {"bem_last_error": ctypes.c_char_p, "bem_pw_packed_elems": c_int64, "bem_selective_scan_bwd_ws_elems": c_int64}
+_RESTYPE = {"bem_last_error": ctypes.c_char_p, "bem_pw_packed_elems": c_int64, "bem_pw_x6_packed_elems": c_int64, "bem_selective_scan_bwd_ws_elems": c_int64}
 
 _lib = None
 

@@ -117,18 +117,29 @@ def ss2d_scan(x0, x1, xd0, xd1, dtw, dtb, A, Ds):
 
 
 # --------------------------------------------------------------------------- pointwise GEMM ---
-def packed_elems(M: int, K: int) -> int:
-    return int(lib().bem_pw_packed_elems(M, K))
+# Two operand formats for the same GEMM contract: "f32" (v_mfma_f32_32x32x2_f32, bem_pw_gemm_f32) and "x6" (three bf16
+# limbs per f32 value, six limb products on v_mfma_f32_32x32x16_bf16, bem_pw_gemm_x6_f32 -- f32-level error at 6/16 of
+# the matrix-pipe cost).  pack_pw_weight picks the format, pw_gemm recognises it from the packed size (the two sizes
+# never coincide: 32 ceil(K/2) vs 768 ceil(K/16) floats per M-tile).  BEM_PW_X6=0 selects the f32 kernels everywhere.
+USE_X6 = __import__("os").environ.get("BEM_PW_X6", "1") != "0"
 
 
-def pack_pw_weight(W):
-    """(M,K) or (nsets,M,K) natural weights -> packed MFMA operand order, shape (nsets, packed)."""
+def packed_elems(M: int, K: int, x6: bool = False) -> int:
+    return int(lib().bem_pw_x6_packed_elems(M, K) if x6 else lib().bem_pw_packed_elems(M, K))
+
+
+def pack_pw_weight(W, x6=None):
+    """(M,K) or (nsets,M,K) natural weights -> packed MFMA operand order, shape (nsets, packed).
+    x6: None = module default (USE_X6), False = f32 operands (also what the MFMA convolution consumes)."""
     _chk(W, "W")
     if W.dim() == 2:
         W = W[None]
     ns, M, K = W.shape
-    out = torch.empty(ns, packed_elems(M, K), device=W.device, dtype=W.dtype)
-    check(lib().bem_pack_pw_weight_f32(_p(W), _p(out), ns, M, K, _stream()), "pack_pw_weight")
+    x6 = USE_X6 if x6 is None else x6
+    out = torch.empty(ns, packed_elems(M, K, x6), device=W.device, dtype=W.dtype)
+    fn = lib().bem_pack_pw_weight_x6 if x6 else lib().bem_pack_pw_weight_f32
+    check(fn(_p(W), _p(out), ns, M, K, _stream()), "pack_pw_weight")
+    out._bem_mk = (M, K)          # the x6 size only pins ceil(K/16): keep the exact logical shape for pw_gemm's check
     return out
 
 
@@ -150,7 +161,10 @@ def pw_gemm(x1, Wp, M, *, x2=None, in_mode=0, ln=None, ln_eps=1e-5, bias=None, r
     K = C1 + C2 if in_mode == 2 else C1
     if in_mode == 1 and C1 != C2:
         raise ValueError("pw_gemm sum mode: channel mismatch")
-    if Wp.dim() != 2 or Wp.shape[1] != packed_elems(M, K) or Wp.shape[0] not in (1, B):
+    x6 = Wp.dim() == 2 and Wp.shape[1] == packed_elems(M, K, True)
+    if getattr(Wp, "_bem_mk", (M, K)) != (M, K):
+        raise ValueError(f"pw_gemm: weights packed for (M, K) = {Wp._bem_mk}, called with M={M} K={K}")
+    if Wp.dim() != 2 or not (x6 or Wp.shape[1] == packed_elems(M, K)) or Wp.shape[0] not in (1, B):
         raise ValueError(f"pw_gemm: packed weight shape {tuple(Wp.shape)} does not match M={M} K={K} B={B}")
     a = PwArgs()
     a.x1, a.x2, a.C1, a.C2, a.in_mode = x1.data_ptr(), (x2.data_ptr() if x2 is not None else 0), C1, C2, in_mode
@@ -187,7 +201,7 @@ def pw_gemm(x1, Wp, M, *, x2=None, in_mode=0, ln=None, ln_eps=1e-5, bias=None, r
         raise ValueError("pw_gemm: out shape")
     a.out = out.data_ptr()
     a.B, a.M, a.K, a.L = B, M, K, L
-    check(lib().bem_pw_gemm_f32(ctypes.byref(a), _stream()), "pw_gemm")
+    check((lib().bem_pw_gemm_x6_f32 if x6 else lib().bem_pw_gemm_f32)(ctypes.byref(a), _stream()), "pw_gemm")
     return out
 
 
@@ -278,7 +292,7 @@ def _packed_conv_weight(w):
         if len(_CONV_PACK) > 256:
             _CONV_PACK.clear()
         # the source tensor is kept alive with its packed copy: a freed-and-reused address must never alias a stale entry
-        hit = (w, pack_pw_weight(w.reshape(w.shape[0], -1).contiguous()))
+        hit = (w, pack_pw_weight(w.reshape(w.shape[0], -1).contiguous(), x6=False))
         _CONV_PACK[key] = hit
     return hit[1]
 

@@ -1,0 +1,603 @@
+// Pointwise (1x1) channel-mix GEMM, f32 in / f32 out, products on the bf16 matrix cores as a 3-limb expansion.
+//
+//   out[b][m][p] = act(sum_k W[m][k] * pro(x)[b][k][p] + bias[m]) + res[b][m][p]        (same contract as pw_gemm.hip)
+//
+// Why: v_mfma_f32_32x32x2_f32 delivers 64 FLOP / cycle / SIMD, v_mfma_f32_32x32x16_bf16 1024.  Every f32 operand is
+// split exactly into three bf16 limbs  v = h + m + l  (round-to-nearest at each step, exact f32 residuals), and a
+// product is evaluated as the six limb products of weight >= 2^-16 relative
+//        x*w ~ xl*wh + xh*wl + xm*wm + xm*wh + xh*wm + xh*wh          (dropped: xm*wl + xl*wm + xl*wl <= 2^-23 |x w|)
+// each of which is exact in the f32 accumulator of the MFMA.  The result carries f32-level error (the dropped terms
+// are of the order of one f32 rounding of the product) at 6/16 of the f32-MFMA cost, which moves these GEMMs from
+// the matrix pipe to the HBM roofline.  Parity tests hold it to the same tolerances as the native-f32 kernels.
+//
+// Mapping (NCHW, pixels on lanes):
+//   * one wave = 32 * NSUB consecutive pixels; lane l owns pixels p0 + NSUB * (l & 31) + t, t < NSUB (one float2 load
+//     per lane and channel for NSUB = 2).  Sub-tile t (pixels with the same t) is one MFMA N-tile.
+//   * k-block kb covers input channels 16 kb .. 16 kb + 15; lanes 0-31 hold channels 16 kb + 0..7, lanes 32-63
+//     channels 16 kb + 8..15 (the B[k = 8 (l >> 5) + e][n = l & 31] layout of the 32x32x16 instruction).
+//   * weights arrive pre-split and pre-packed by bem_pack_pw_weight_x6: Wp[mtile][kb][limb][lane] is one 16-byte
+//     vector = W[32 mtile + (lane & 31)][16 kb + 8 (lane >> 5) + e], e = 0..7, so an A operand is one coalesced
+//     1 KiB load per (M-tile, k-block, limb), L1/L2 resident.
+//   * D layout: column = lane & 31 (pixel), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+//   * "resident" kernel: the wave's whole input tile (all K channels, already normalised and split) stays in
+//     registers while the wave walks over every M-tile, so x is read once and LayerNorm evaluated once;
+//     "stream" kernel (no LayerNorm, any K): x is streamed k-block by k-block, one block ahead of the MFMAs.
+#include "bem_common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct PwX {
+    const float* x1; const float* x2; int C1; int C2; int in_mode;
+    const float* ln_w; const float* ln_b; float ln_eps;
+    const u32x4* Wp; int64_t w_bstride;       // stride in 16-byte vectors
+    const float* bias; int64_t bias_bstride;
+    const float* res; const float* prelu; int act;
+    float* out; int out_mode; int Win;
+    int M; int K; int L; int KB; int MT;
+    int dbg;   // timing experiments (BEM_PW_DBG): bit0 skip MFMAs, bit1 suppress stores
+};
+
+__device__ __forceinline__ uint32_t fbits(float v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ float bitsf(uint32_t u) { return __builtin_bit_cast(float, u); }
+
+// Workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2).  Give every XCD a contiguous run of pixel
+// tiles so that the chunks one L2 collects (and later writes back) for a plane are adjacent in memory.
+__device__ __forceinline__ int xcd_tile(int x, int nx) {
+    const int per = nx >> 3, rem = nx & 7, xcd = x & 7, idx = x >> 3;
+    return xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
+}
+
+// exact 3-limb split of 8 values (the lane's 8 channels of one k-block and sub-tile) into three MFMA operands.
+// Limbs are taken by round-to-nearest-even (v_cvt_pk_bf16_f32, two values per instruction): |m| <= 2^-8 |v|,
+// |l| <= 2^-16 |v|, the residuals are exact in f32, and the limb products the GEMM drops (m*l, l*m, l*l) are
+// <= 2^-23 |x w| with no preferred sign.  (Truncated limbs are twice as large and all carry the sign of v: the same
+// six products then leave a biased 2^-21 error.)
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4& h, u32x4& m, u32x4& l) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x2 a = {v[2 * q], v[2 * q + 1]};
+        const uint32_t uh = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2));
+        const f32x2 r1 = {a[0] - bitsf(uh << 16), a[1] - bitsf(uh & 0xffff0000u)};
+        const uint32_t um = __builtin_bit_cast(uint32_t, __builtin_convertvector(r1, bf16x2));
+        const f32x2 r2 = {r1[0] - bitsf(um << 16), r1[1] - bitsf(um & 0xffff0000u)};
+        h[q] = uh;
+        m[q] = um;
+        l[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r2, bf16x2));
+    }
+}
+
+__device__ __forceinline__ f32x16 mfma16(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// The six limb products in two accumulators: `hi` takes xh*wh (16-bit significands, magnitude of the result), `lo` the
+// five products that are <= 2^-8 of it.  Feeding the small products straight into the large accumulator loses their
+// low bits in the MFMA's addend alignment -- always downwards, a bias of ~1e-8 per output that adds up coherently over a
+// network; kept apart they are summed among their own size and joined to `hi` by one rounded f32 add in the epilogue.
+__device__ __forceinline__ void mac6(const u32x4 (&w)[3], const u32x4 (&x)[3], f32x16& hi, f32x16& lo, int dbg = 0) {
+    if (dbg & 1) { hi[0] += bitsf(w[0][0] ^ x[0][0] ^ w[1][1] ^ x[1][1] ^ w[2][2] ^ x[2][2]); return; }
+    lo = mfma16(w[0], x[2], lo);
+    lo = mfma16(w[2], x[0], lo);
+    lo = mfma16(w[1], x[1], lo);
+    lo = mfma16(w[0], x[1], lo);
+    lo = mfma16(w[1], x[0], lo);
+    hi = mfma16(w[0], x[0], hi);
+}
+
+// Branch-free input fetch (see pw_gemm.hip): always a clamped, valid address, value masked afterwards.
+// Returns pro-input channel ch at this lane's NSUB pixels (pixel index pc clamped by the caller, keep[t] per pixel).
+template <int NSUB, bool SUM, bool VEC>
+__device__ __forceinline__ void ldx(const PwX& k, int b, int ch, int pc, const bool (&keep)[NSUB], float (&o)[NSUB]) {
+    const int chc = min(ch, k.K - 1);
+    const bool first = chc < k.C1;
+    const float* r1 = k.x1 + ((int64_t)b * k.C1 + (first ? chc : 0)) * k.L;
+    const float* r2 = k.x2 + ((int64_t)b * k.C2 + (first ? 0 : chc - k.C1)) * k.L;
+    const float* base = first ? r1 : r2;
+    const float* sec = k.x2 + ((int64_t)b * k.C2 + chc) * k.L;     // only dereferenced when SUM
+    if (NSUB == 2 && VEC) {
+        float2 v = *reinterpret_cast<const float2*>(base + pc);
+        if (SUM) { const float2 w = *reinterpret_cast<const float2*>(sec + pc); v.x += w.x; v.y += w.y; }
+        o[0] = v.x; o[NSUB - 1] = v.y;
+    } else {
+#pragma unroll
+        for (int t = 0; t < NSUB; ++t) {
+            const int pi = min(pc + t, k.L - 1);
+            o[t] = base[pi];
+            if (SUM) o[t] += sec[pi];
+        }
+    }
+    const float mk = ch < k.K ? 1.f : 0.f;
+#pragma unroll
+    for (int t = 0; t < NSUB; ++t) o[t] = keep[t] ? o[t] * mk : 0.f;
+}
+
+// bias comes from LDS (s_bias, zero-filled without a bias), the residual is fetched under ONE uniform branch per batch
+// of rows: every global round trip in here is latency the wave cannot hide (2 waves per SIMD), so there is none
+// unless a residual is actually present.
+template <int MTW, int NSUB, bool VEC>
+__device__ __forceinline__ void x6_epilogue_generic(const PwX& k, int b, int mt0, int p, const bool (&keep)[NSUB], int kh,
+                                                    const float* __restrict__ s_bias, const f32x16 (&acc)[MTW][NSUB]) {
+    const float slope = (k.act == 1) ? k.prelu[0] : 0.f;
+    const bool has_res = k.res && k.out_mode == 0;
+    const float* resp = k.res + (int64_t)b * k.M * k.L;
+    const int pv = VEC ? (keep[0] ? p : 0) : p;
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+        if (mt0 + m >= k.MT) continue;
+        const int rbase = (mt0 + m) * 32 + 4 * kh;
+#pragma unroll
+        for (int rh = 0; rh < 16; rh += 8) {
+            float rv[8][NSUB];
+#pragma unroll
+            for (int r8 = 0; r8 < 8; ++r8)
+#pragma unroll
+                for (int t = 0; t < NSUB; ++t) rv[r8][t] = 0.f;
+            if (has_res) {
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8) {
+                    const int r = rh + r8;
+                    const float* rp = resp + (int64_t)min(rbase + (r & 3) + 8 * (r >> 2), k.M - 1) * k.L;
+                    if (NSUB == 2 && VEC) {
+                        const float2 q = *reinterpret_cast<const float2*>(rp + pv);
+                        rv[r8][0] = q.x; rv[r8][NSUB - 1] = q.y;
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < NSUB; ++t) rv[r8][t] = rp[min(pv + t, k.L - 1)];
+                    }
+                }
+            }
+#pragma unroll
+            for (int r8 = 0; r8 < 8; ++r8) {
+                const int r = rh + r8;
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (row >= k.M) continue;
+                const float bv = s_bias[row];
+                float o[NSUB];
+#pragma unroll
+                for (int t = 0; t < NSUB; ++t) {
+                    o[t] = acc[m][t][r] + bv;
+                    if (k.act == 1) o[t] = o[t] >= 0.f ? o[t] : slope * o[t];
+                    o[t] += rv[r8][t];
+                }
+                if (k.out_mode == 0) {
+                    float* op = k.out + ((int64_t)b * k.M + row) * k.L + p;
+                    if (NSUB == 2 && VEC) {
+                        if (keep[0] && (!(k.dbg & 2) || o[0] == 123.456f)) *reinterpret_cast<float2*>(op) = make_float2(o[0], o[NSUB - 1]);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < NSUB; ++t)
+                            if (keep[t]) op[t] = o[t];
+                    }
+                } else {
+                    const int Co = k.M >> 2;
+                    const int q = row / Co, co = row - q * Co;
+                    const int64_t obase = ((int64_t)b * Co + co) * (4 * (int64_t)k.L);
+#pragma unroll
+                    for (int t = 0; t < NSUB; ++t) {
+                        if (keep[t]) {
+                            const int pp = p + t;
+                            const int yy = pp / k.Win, xx = pp - yy * k.Win;
+                            k.out[obase + (int64_t)(2 * yy + (q >> 1)) * (2 * k.Win) + (2 * xx + (q & 1))] = o[t];
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// out_mode 0 epilogue with the address arithmetic kept off the vector ALU: a row's plane base is wave-uniform (scalar
+// registers), the lane contributes one 32-bit element offset computed once (its pixel and its 4-row half), so a store
+// is `global_store v_off, v_data, s[base]`; the 16 bias values of an M-tile come as four LDS float4 reads.  PReLU and
+// the residual are compile-time variants (chosen by uniform branches in x6_epilogue): without them a value costs one add.
+template <int MTW, int NSUB, bool VEC, bool ACT, bool RES>
+__device__ __forceinline__ void x6_epilogue_rows(const PwX& k, int b, int mt0, int p, const bool (&keep)[NSUB], int kh,
+                                                 const float* __restrict__ s_bias, const f32x16 (&acc)[MTW][NSUB]) {
+    const float slope = ACT ? k.prelu[0] : 0.f;
+    const int pv = VEC ? (keep[0] ? p : 0) : min(p, k.L - 1);
+    const uint32_t loff = (uint32_t)(4 * kh) * (uint32_t)k.L + (uint32_t)pv;
+    float* outb = k.out + (int64_t)b * k.M * k.L;
+    const float* resb = RES ? k.res + (int64_t)b * k.M * k.L : nullptr;
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+        if (mt0 + m >= k.MT) continue;
+        const int rb = (mt0 + m) * 32;                        // uniform
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bq = *reinterpret_cast<const float4*>(s_bias + rb + 8 * g + 4 * kh);
+            const float bv[4] = {bq.x, bq.y, bq.z, bq.w};
+            float rv[4][NSUB];
+            if (RES) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int urow = rb + 8 * g + i;
+                    const float* rp = resb + (int64_t)min(urow, k.M - 1) * k.L;          // uniform plane base, clamped
+                    const uint32_t lo = urow + 4 * kh < k.M ? loff : (uint32_t)pv;        // rows >= M (never stored) read a valid row
+                    if (NSUB == 2 && VEC) {
+                        const float2 q = *reinterpret_cast<const float2*>(rp + lo);
+                        rv[i][0] = q.x; rv[i][NSUB - 1] = q.y;
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < NSUB; ++t) rv[i][t] = rp[lo + (pv + t < k.L ? t : 0)];
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * g + i;
+                const int urow = rb + 8 * g + i;              // uniform; this lane's row = urow + 4 kh
+                float o[NSUB];
+#pragma unroll
+                for (int t = 0; t < NSUB; ++t) {
+                    o[t] = acc[m][t][r] + bv[i];
+                    if (ACT) o[t] = o[t] >= 0.f ? o[t] : slope * o[t];
+                    if (RES) o[t] += rv[i][t];
+                }
+                float* op = outb + (int64_t)urow * k.L;
+                const bool rowok = urow + 4 * kh < k.M;
+                if (NSUB == 2 && VEC) {
+                    if (keep[0] && rowok) *reinterpret_cast<float2*>(op + loff) = make_float2(o[0], o[NSUB - 1]);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NSUB; ++t)
+                        if (keep[t] && rowok) op[loff + t] = o[t];
+                }
+            }
+        }
+    }
+}
+
+template <int MTW, int NSUB, bool VEC>
+__device__ __forceinline__ void x6_epilogue(const PwX& k, int b, int mt0, int p, const bool (&keep)[NSUB], int kh,
+                                            const float* __restrict__ s_bias, const f32x16 (&acc)[MTW][NSUB]) {
+    if (k.out_mode != 0 || k.M < 8) { x6_epilogue_generic<MTW, NSUB, VEC>(k, b, mt0, p, keep, kh, s_bias, acc); return; }
+    const bool act = k.act == 1, res = k.res != nullptr;      // uniform
+    if (!act && !res) x6_epilogue_rows<MTW, NSUB, VEC, false, false>(k, b, mt0, p, keep, kh, s_bias, acc);
+    else if (!act) x6_epilogue_rows<MTW, NSUB, VEC, false, true>(k, b, mt0, p, keep, kh, s_bias, acc);
+    else if (!res) x6_epilogue_rows<MTW, NSUB, VEC, true, false>(k, b, mt0, p, keep, kh, s_bias, acc);
+    else x6_epilogue_rows<MTW, NSUB, VEC, true, true>(k, b, mt0, p, keep, kh, s_bias, acc);
+}
+
+// bias of this batch row -> LDS (zeros without a bias); M <= BEM_X6_MAXM
+constexpr int BEM_X6_MAXM = 2048;
+__device__ __forceinline__ void stage_bias(const PwX& k, int b, float* s_bias) {
+    const float* bias = k.bias ? k.bias + (int64_t)b * k.bias_bstride : nullptr;
+    for (int i = threadIdx.x; i < k.MT * 32; i += 256) s_bias[i] = (bias && i < k.M) ? bias[i] : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// resident: K <= 16 * KBM.  grid (ceil(L / (128 * NSUB)), 1, B), 4 independent waves per workgroup.
+// ------------------------------------------------------------------------------------------------
+template <int KBM, int NSUB, int MTW, bool SUM, bool VEC>
+__global__ __launch_bounds__(256, 2) void pw_x6_res_kernel(PwX k) {
+    __shared__ float s_ln[2 * 16 * KBM];
+    __shared__ __attribute__((aligned(16))) float s_bias[BEM_X6_MAXM];
+    stage_bias(k, blockIdx.z, s_bias);
+    for (int i = threadIdx.x; i < 16 * KBM; i += 256) {
+        const bool on = k.ln_w && i < k.K;
+        s_ln[i] = on ? k.ln_w[min(i, k.K - 1)] : 0.f;
+        s_ln[16 * KBM + i] = on ? k.ln_b[min(i, k.K - 1)] : 0.f;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kh = lane >> 5, n = lane & 31;
+    const int b = blockIdx.z;
+    const int p0 = (xcd_tile(blockIdx.x, gridDim.x) * 4 + wave) * (32 * NSUB);
+    const int p = p0 + NSUB * n;
+    bool keep[NSUB];
+#pragma unroll
+    for (int t = 0; t < NSUB; ++t) keep[t] = p + t < k.L;
+    // VEC (L even, p even): both pixels are kept or neither -> read at p or at 0; scalar form: ldx clamps every pixel itself
+    const int pc = VEC ? (keep[0] ? p : 0) : p;
+    float xr[KBM][8][NSUB];
+#pragma unroll
+    for (int kb = 0; kb < KBM; ++kb)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ldx<NSUB, SUM, VEC>(k, b, 16 * kb + 8 * kh + e, pc, keep, xr[kb][e]);
+    __syncthreads();                                            // s_ln visible (the only barrier; before any early exit)
+    if (p0 >= k.L) return;
+    if (k.ln_w) {
+        const float inv = 1.f / (float)k.K;
+        float mean[NSUB], rstd[NSUB];
+#pragma unroll
+        for (int t = 0; t < NSUB; ++t) {
+            float s = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < KBM; ++kb)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += xr[kb][e][t];
+            s += __shfl_xor(s, 32, 64);
+            mean[t] = s * inv;
+            float q = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < KBM; ++kb)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = (16 * kb + 8 * kh + e < k.K) ? xr[kb][e][t] - mean[t] : 0.f;     // padded channels do not count
+                    q = fmaf(d, d, q);
+                }
+            q += __shfl_xor(q, 32, 64);
+            rstd[t] = 1.f / sqrtf(q * inv + k.ln_eps);
+        }
+#pragma unroll
+        for (int kb = 0; kb < KBM; ++kb)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float g = s_ln[16 * kb + 8 * kh + e], be = s_ln[16 * KBM + 16 * kb + 8 * kh + e];   // 0 on padded channels
+#pragma unroll
+                for (int t = 0; t < NSUB; ++t) xr[kb][e][t] = (xr[kb][e][t] - mean[t]) * rstd[t] * g + be;
+            }
+    }
+    u32x4 xl[KBM][NSUB][3];
+#pragma unroll
+    for (int kb = 0; kb < KBM; ++kb)
+#pragma unroll
+        for (int t = 0; t < NSUB; ++t) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = xr[kb][e][t];
+            split8(v, xl[kb][t][0], xl[kb][t][1], xl[kb][t][2]);
+        }
+    const u32x4* wbase = k.Wp + (int64_t)b * k.w_bstride + lane;
+    const int64_t mt_stride = (int64_t)k.KB * 3 * 64;           // vectors per M-tile
+    // weights one k-block ahead of the MFMAs, across M-tile groups too (the first block of the next group is requested
+    // before the epilogue of this one); k-blocks beyond KB and M-tiles beyond MT re-read a valid block and are masked to zero
+    auto load_w = [&](int mt, int kb, u32x4 (&dst)[MTW][3]) {
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            const bool ok = kb < k.KB && mt + m < k.MT;
+            const u32x4* wp = wbase + (int64_t)(mt + m < k.MT ? mt + m : 0) * mt_stride + (int64_t)min(kb, k.KB - 1) * 3 * 64;
+            const uint32_t mk = ok ? 0xffffffffu : 0u;
+#pragma unroll
+            for (int li = 0; li < 3; ++li) {
+                const u32x4 w = wp[li * 64];
+                dst[m][li] = u32x4{w[0] & mk, w[1] & mk, w[2] & mk, w[3] & mk};
+            }
+        }
+    };
+    u32x4 wn[MTW][3];
+    load_w(0, 0, wn);
+    for (int mt0 = 0; mt0 < k.MT; mt0 += MTW) {
+        f32x16 acc[MTW][NSUB], alo[MTW][NSUB];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int t = 0; t < NSUB; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][t][r] = alo[m][t][r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < KBM; ++kb) {
+            u32x4 wc[MTW][3];
+#pragma unroll
+            for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                for (int li = 0; li < 3; ++li) wc[m][li] = wn[m][li];
+            if (kb + 1 < KBM) load_w(mt0, kb + 1, wn);
+            else load_w(mt0 + MTW, 0, wn);
+#pragma unroll
+            for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                for (int t = 0; t < NSUB; ++t) mac6(wc[m], xl[kb][t], acc[m][t], alo[m][t], k.dbg);
+        }
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int t = 0; t < NSUB; ++t) acc[m][t] += alo[m][t];
+        x6_epilogue<MTW, NSUB, VEC>(k, b, mt0, p, keep, kh, s_bias, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stream: any K, no LayerNorm.  grid (ceil(L / 256), ceil(MT / MTW), B); x one k-block ahead of the MFMAs.
+// ------------------------------------------------------------------------------------------------
+constexpr int BEM_X6_MAXK_LN = 1024;      // LayerNorm parameters of the streaming form live in LDS
+template <int MTW, bool SUM, bool VEC, bool LN>
+__global__ __launch_bounds__(256, 2) void pw_x6_stream_kernel(PwX k) {
+    constexpr int NSUB = 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kh = lane >> 5, n = lane & 31;
+    const int b = blockIdx.z, mt0 = blockIdx.y * MTW;
+    const int p0 = (xcd_tile(blockIdx.x, gridDim.x) * 4 + wave) * 64;
+    __shared__ __attribute__((aligned(16))) float s_bias[BEM_X6_MAXM];
+    __shared__ float s_ln[LN ? 2 * BEM_X6_MAXK_LN : 2];
+    stage_bias(k, b, s_bias);
+    if (LN) {
+        for (int i = threadIdx.x; i < k.KB * 16; i += 256) {     // zero scale / shift on the padded channels
+            s_ln[i] = i < k.K ? k.ln_w[i] : 0.f;
+            s_ln[BEM_X6_MAXK_LN + i] = i < k.K ? k.ln_b[i] : 0.f;
+        }
+    }
+    __syncthreads();                    // the only barrier, before any early exit
+    if (p0 >= k.L) return;
+    const int p = p0 + 2 * n;
+    bool keep[NSUB];
+#pragma unroll
+    for (int t = 0; t < NSUB; ++t) keep[t] = p + t < k.L;
+    const int pc = VEC ? (keep[0] ? p : 0) : p;
+    auto load_x = [&](int kb, float (&dst)[8][NSUB]) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ldx<NSUB, SUM, VEC>(k, b, 16 * kb + 8 * kh + e, pc, keep, dst[e]);   // channels >= K come back as zeros
+    };
+    // LayerNorm over K larger than the register-resident forms hold: statistics in a first sweep over the channels
+    // (mean, then centred variance -- the second and third reads of x come from L1 / L2), normalisation on the fly below
+    float mean[NSUB], rstd[NSUB];
+    if (LN) {
+        const float inv = 1.f / (float)k.K;
+        float s[NSUB] = {0.f, 0.f};
+        for (int kb = 0; kb < k.KB; ++kb) {
+            float v[8][NSUB];
+            load_x(kb, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int t = 0; t < NSUB; ++t) s[t] += v[e][t];
+        }
+#pragma unroll
+        for (int t = 0; t < NSUB; ++t) { s[t] += __shfl_xor(s[t], 32, 64); mean[t] = s[t] * inv; }
+        float q[NSUB] = {0.f, 0.f};
+        for (int kb = 0; kb < k.KB; ++kb) {
+            float v[8][NSUB];
+            load_x(kb, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float mk = (16 * kb + 8 * kh + e < k.K) ? 1.f : 0.f;
+#pragma unroll
+                for (int t = 0; t < NSUB; ++t) { const float d = (v[e][t] - mean[t]) * mk; q[t] = fmaf(d, d, q[t]); }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NSUB; ++t) { q[t] += __shfl_xor(q[t], 32, 64); rstd[t] = 1.f / sqrtf(q[t] * inv + k.ln_eps); }
+    }
+    f32x16 acc[MTW][NSUB], alo[MTW][NSUB];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int t = 0; t < NSUB; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][t][r] = alo[m][t][r] = 0.f;
+    const u32x4* wbase = k.Wp + (int64_t)b * k.w_bstride + lane;
+    const int64_t mt_stride = (int64_t)k.KB * 3 * 64;
+    auto load_w = [&](int kb, u32x4 (&dst)[MTW][3]) {
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            const bool ok = kb < k.KB && mt0 + m < k.MT;
+            const u32x4* wp = wbase + (int64_t)(mt0 + m < k.MT ? mt0 + m : 0) * mt_stride + (int64_t)min(kb, k.KB - 1) * 3 * 64;
+            const uint32_t mk = ok ? 0xffffffffu : 0u;
+#pragma unroll
+            for (int li = 0; li < 3; ++li) {
+                const u32x4 w = wp[li * 64];
+                dst[m][li] = u32x4{w[0] & mk, w[1] & mk, w[2] & mk, w[3] & mk};
+            }
+        }
+    };
+    float xn[8][NSUB];
+    u32x4 wn[MTW][3];
+    load_x(0, xn);
+    load_w(0, wn);
+    for (int kb = 0; kb < k.KB; ++kb) {
+        u32x4 xl[NSUB][3], wc[MTW][3];
+#pragma unroll
+        for (int t = 0; t < NSUB; ++t) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[e] = xn[e][t];
+                if (LN) v[e] = (v[e] - mean[t]) * rstd[t] * s_ln[16 * kb + 8 * kh + e] + s_ln[BEM_X6_MAXK_LN + 16 * kb + 8 * kh + e];
+            }
+            split8(v, xl[t][0], xl[t][1], xl[t][2]);
+        }
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int li = 0; li < 3; ++li) wc[m][li] = wn[m][li];
+        load_x(kb + 1, xn);          // past the end: clamped channel, masked to zero, never used
+        load_w(kb + 1, wn);
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int t = 0; t < NSUB; ++t) mac6(wc[m], xl[t], acc[m][t], alo[m][t], k.dbg);
+    }
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int t = 0; t < NSUB; ++t) acc[m][t] += alo[m][t];
+    x6_epilogue<MTW, NSUB, VEC>(k, b, mt0, p, keep, kh, s_bias, acc);
+}
+
+// natural (nsets, M, K) f32 -> (nsets, MT, KB, 3, 64) 16-byte vectors of bf16 limbs
+__global__ void pack_x6_kernel(const float* __restrict__ W, u32x4* __restrict__ Wp, int M, int K, int MT, int KB, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int lane = (int)(i & 63);
+    const int64_t blk = i >> 6;
+    const int kb = (int)(blk % KB), mt = (int)((blk / KB) % MT);
+    const int64_t set = blk / ((int64_t)KB * MT);
+    const int row = mt * 32 + (lane & 31), k0 = kb * 16 + (lane >> 5) * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (row < M && k0 + e < K) ? W[(set * M + row) * K + k0 + e] : 0.f;
+    u32x4 h, m, l;
+    split8(v, h, m, l);
+    u32x4* o = Wp + ((set * MT + mt) * KB + kb) * 3 * 64 + lane;
+    o[0] = h; o[64] = m; o[128] = l;
+}
+
+}  // namespace
+
+extern "C" int64_t bem_pw_x6_packed_elems(int M, int K) {       // in floats (4 per 16-byte vector)
+    return (int64_t)cdiv(M, 32) * cdiv(K, 16) * 3 * 64 * 4;
+}
+
+extern "C" int bem_pack_pw_weight_x6(const float* W, float* Wp, int nsets, int M, int K, void* stream) {
+    BEM_REQUIRE(W && Wp, "pack_pw_weight_x6: null tensor");
+    BEM_REQUIRE(nsets >= 0 && M > 0 && K > 0, "pack_pw_weight_x6: bad shape");
+    BEM_REQUIRE(((uintptr_t)Wp & 15) == 0, "pack_pw_weight_x6: output must be 16-byte aligned");
+    if (nsets == 0) return BEM_OK;
+    const int MT = cdiv(M, 32), KB = cdiv(K, 16);
+    const int64_t total = (int64_t)nsets * MT * KB * 64;
+    pack_x6_kernel<<<(unsigned)cdiv64(total, 256), 256, 0, (hipStream_t)stream>>>(W, reinterpret_cast<u32x4*>(Wp), M, K, MT, KB, total);
+    return bem_check_launch("pack_pw_weight_x6");
+}
+
+extern "C" int bem_pw_gemm_x6_f32(const bem_pw_args* a, void* stream) {
+    BEM_REQUIRE(a, "pw_gemm_x6: null args");
+    BEM_REQUIRE(a->x1 && a->Wp && a->out, "pw_gemm_x6: null tensor");
+    BEM_REQUIRE(a->B >= 0 && a->B <= 65535 && a->M > 0 && a->M <= BEM_X6_MAXM && a->K > 0 && a->L >= 0, "pw_gemm_x6: bad shape B=%d M=%d K=%d L=%d", a->B, a->M, a->K, a->L);
+    BEM_REQUIRE(a->in_mode >= 0 && a->in_mode <= 2, "pw_gemm_x6: in_mode %d", a->in_mode);
+    if (a->in_mode == 0) BEM_REQUIRE(a->K == a->C1, "pw_gemm_x6: K %d != C1 %d", a->K, a->C1);
+    if (a->in_mode == 1) BEM_REQUIRE(a->x2 && a->K == a->C1 && a->C1 == a->C2, "pw_gemm_x6: sum mode needs x2 and K == C1 == C2");
+    if (a->in_mode == 2) BEM_REQUIRE(a->x2 && a->K == a->C1 + a->C2, "pw_gemm_x6: cat mode needs x2 and K == C1 + C2");
+    BEM_REQUIRE((a->ln_w == nullptr) == (a->ln_b == nullptr), "pw_gemm_x6: ln_w / ln_b must both be set or both NULL");
+    BEM_REQUIRE(a->act == 0 || (a->act == 1 && a->prelu), "pw_gemm_x6: act %d", a->act);
+    BEM_REQUIRE(a->out_mode == 0 || (a->out_mode == 1 && a->M % 4 == 0 && a->Win > 0 && a->L % a->Win == 0 && !a->res),
+                "pw_gemm_x6: out_mode %d constraints", a->out_mode);
+    BEM_REQUIRE(((uintptr_t)a->Wp & 15) == 0 && a->w_bstride % 4 == 0, "pw_gemm_x6: packed weights must be 16-byte aligned");
+    BEM_REQUIRE((int64_t)a->M * a->L < (1ll << 30), "pw_gemm_x6: M * L = %lld exceeds the 32-bit lane offsets of the epilogue", (long long)a->M * a->L);
+    const bool ln = a->ln_w != nullptr;
+    BEM_REQUIRE(!ln || a->K <= BEM_X6_MAXK_LN, "pw_gemm_x6: LayerNorm prologue supports K <= %d (got %d)", BEM_X6_MAXK_LN, a->K);
+    if (a->B == 0 || a->L == 0) return BEM_OK;
+    PwX k;
+    k.x1 = a->x1; k.x2 = a->x2 ? a->x2 : a->x1; k.C1 = a->C1; k.C2 = a->x2 ? a->C2 : a->C1; k.in_mode = a->in_mode;
+    k.ln_w = a->ln_w; k.ln_b = a->ln_b; k.ln_eps = a->ln_eps;
+    k.Wp = reinterpret_cast<const u32x4*>(a->Wp); k.w_bstride = a->w_bstride / 4; k.bias = a->bias; k.bias_bstride = a->bias_bstride;
+    k.res = a->res; k.prelu = a->prelu; k.act = a->act; k.out = a->out; k.out_mode = a->out_mode; k.Win = a->Win;
+    k.M = a->M; k.K = a->K; k.L = a->L; k.KB = cdiv(a->K, 16); k.MT = cdiv(a->M, 32);
+    static const int pw_dbg = getenv("BEM_PW_DBG") ? atoi(getenv("BEM_PW_DBG")) : 0;
+    k.dbg = pw_dbg;
+    hipStream_t s = (hipStream_t)stream;
+    const bool sum = a->in_mode == 1;
+    const bool al = (((uintptr_t)a->x1 | (uintptr_t)(a->x2 ? a->x2 : a->x1) | (uintptr_t)a->out | (uintptr_t)(a->res ? a->res : a->out)) & 7) == 0;
+    const bool vec = a->L % 2 == 0 && al;
+#define BEM_X6_RES(KBM, NSUB, MTW)                                                                       \
+    do {                                                                                                 \
+        dim3 grid(cdiv(a->L, 128 * NSUB), 1, a->B);                                                      \
+        if (NSUB == 2 && vec && !sum) pw_x6_res_kernel<KBM, NSUB, MTW, false, true><<<grid, 256, 0, s>>>(k);   \
+        else if (NSUB == 2 && vec) pw_x6_res_kernel<KBM, NSUB, MTW, true, true><<<grid, 256, 0, s>>>(k);       \
+        else if (!sum) pw_x6_res_kernel<KBM, NSUB, MTW, false, false><<<grid, 256, 0, s>>>(k);                 \
+        else pw_x6_res_kernel<KBM, NSUB, MTW, true, false><<<grid, 256, 0, s>>>(k);                            \
+        return bem_check_launch("pw_x6_res");                                                            \
+    } while (0)
+    // one M-tile at a time where a wave holds two sub-tiles: the accumulator pairs double the register cost of an M-tile
+    if (k.KB <= 3) BEM_X6_RES(3, 2, 1);
+    if (ln && k.KB <= 5) BEM_X6_RES(5, 2, 1);
+    if (ln && k.KB <= 10) { if (k.MT == 1) BEM_X6_RES(10, 1, 1); else BEM_X6_RES(10, 1, 2); }
+#undef BEM_X6_RES
+    {
+        const int mtw = k.MT == 1 ? 1 : 2;         // two M-tiles per pass over x: every extra grid.y slice re-reads the input
+        dim3 grid(cdiv(a->L, 256), cdiv(k.MT, mtw), a->B);
+#define BEM_X6_STREAM(MTW, LN)                                                                \
+    do {                                                                                      \
+        if (vec && !sum) pw_x6_stream_kernel<MTW, false, true, LN><<<grid, 256, 0, s>>>(k);   \
+        else if (vec) pw_x6_stream_kernel<MTW, true, true, LN><<<grid, 256, 0, s>>>(k);       \
+        else if (!sum) pw_x6_stream_kernel<MTW, false, false, LN><<<grid, 256, 0, s>>>(k);    \
+        else pw_x6_stream_kernel<MTW, true, false, LN><<<grid, 256, 0, s>>>(k);               \
+    } while (0)
+        if (ln) { if (mtw == 1) BEM_X6_STREAM(1, true); else BEM_X6_STREAM(2, true); }
+        else { if (mtw == 1) BEM_X6_STREAM(1, false); else BEM_X6_STREAM(2, false); }
+#undef BEM_X6_STREAM
+    }
+    return bem_check_launch("pw_x6_stream");
+}

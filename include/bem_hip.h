@@ -104,6 +104,16 @@ int bem_pw_gemm_f32(const bem_pw_args* a, void* stream);
 int bem_pack_pw_weight_f32(const float* W, float* Wp, int nsets, int M, int K, void* stream);
 int64_t bem_pw_packed_elems(int M, int K);
 
+/* The same GEMM contract (bem_pw_args, identical semantics and error behaviour) with the products evaluated on the
+ * bf16 matrix cores as an exact 3-limb expansion of both f32 operands (six limb products per term, f32 accumulate;
+ * the dropped terms are <= 2^-23 of a product, i.e. f32-level error) -- 6/16 of the f32-MFMA cost.
+ * Wp must come from bem_pack_pw_weight_x6: natural (nsets, M, K) f32 -> (nsets, MT, KB, 3 limbs, 64 lanes) 16-byte vectors
+ * of 8 bf16, MT = ceil(M/32), KB = ceil(K/16); bem_pw_x6_packed_elems(M, K) = floats per set (w_bstride unit), 16-byte
+ * aligned.  LayerNorm prologue for K <= 160. */
+int bem_pw_gemm_x6_f32(const bem_pw_args* a, void* stream);
+int bem_pack_pw_weight_x6(const float* W, float* Wp, int nsets, int M, int K, void* stream);
+int64_t bem_pw_x6_packed_elems(int M, int K);
+
 /* ---------------------------------------------------------------------------------------------
  * Fused gdMlp block (vmamba.py:116-133 + the norm2 / residual around it, vmamba.py:1330-1333):
  *   out = x + Wo * (GELU(dw3x3(h)[0:Hd]) * dw3x3(h)[Hd:2Hd]) + bo,  h = Wi * LayerNorm_C(x) + bi

@@ -352,7 +352,7 @@ def test_gdmlp_fused_vs_oracle(ops, cfg):
     lw, lb = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
     ref = x + O.gdmlp_ref(sd, "", O.layernorm2d_ref(x, lw, lb))
     Wpi = ops.pack_pw_weight_gate(dev(sd["project_in.weight"].reshape(2 * Hd, C)), Hd)
-    Wpo = ops.pack_pw_weight(dev(sd["project_out.weight"].reshape(C, Hd)))
+    Wpo = ops.pack_pw_weight(dev(sd["project_out.weight"].reshape(C, Hd)), x6=False)
     y = ops.gdmlp_fused(dev(x), dev(lw), dev(lb), 1e-5, Wpi, dev(sd["project_in.bias"]), dev(sd["dwconv.weight"].reshape(2 * Hd, 9)),
                         dev(sd["dwconv.bias"]), Wpo, dev(sd["project_out.bias"]), Hd)
     close(y, ref, 2e-4, 5e-5, f"gdmlp fused {cfg}")
@@ -371,7 +371,7 @@ def test_gdmlp_fused_per_batch_weights(ops):
                                                "dwconv.bias": bd[i], "project_out.weight": wo[i][:, :, None, None], "project_out.bias": bo[i]},
                                               "", O.layernorm2d_ref(x[i:i + 1], lw, lb)) for i in range(B)])
     y = ops.gdmlp_fused(dev(x), dev(lw), dev(lb), 1e-5, ops.pack_pw_weight_gate(dev(wi), Hd), dev(bi), dev(wd.reshape(B, 2 * Hd * 9)), dev(bd),
-                        ops.pack_pw_weight(dev(wo)), dev(bo), Hd)
+                        ops.pack_pw_weight(dev(wo), x6=False), dev(bo), Hd)
     close(y, ref, 2e-4, 5e-5, "gdmlp fused per-batch")
 
 
