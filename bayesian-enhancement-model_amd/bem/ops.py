@@ -576,8 +576,15 @@ def select_best(final, psnr, samples_per_image):
 _PROF = None
 # profile key -> (op wrapper it belongs to, roofline bound, kernel symbol reported to bench.py, predicate on the call)
 _KEYS = {
-    # the register-resident LN+GEMM kernel with >= 2 M-tiles (in_proj / out_proj / project_in at C <= 40)
-    # (vectorised, single-input form: L % 4 == 0, in_mode 0 or 2 -- the variant every level-0 in_proj / project_in runs)
+    # the register-resident x6 GEMM for K <= 48 (level-0 in_proj / project_in / x_proj and the small Stage-I layers):
+    # every launch of the (vectorised, single-input or concat) instance, whatever M and L
+    "pw_x6_res<3,2,1>": ("pw_gemm", "hbm", "pw_x6_res_kernel<3, 2, 1, false, true>",
+                         lambda K, M, ln, L, mode: USE_X6 and K <= 48 and L % 2 == 0 and mode != 1),
+    # the streaming x6 GEMM with two M-tiles per pass (project_out / out_proj / fuse 1x1 at K > 48 without LayerNorm):
+    # the kernel with the largest share of the step in profiles/r01_bench_kernel_stats.csv
+    "pw_x6_stream<2>": ("pw_gemm", "hbm", "pw_x6_stream_kernel<2, false, true, false>",
+                        lambda K, M, ln, L, mode: USE_X6 and K > 48 and not ln and M > 32 and L % 2 == 0 and mode != 1),
+    # the same role in the f32-MFMA build (BEM_PW_X6=0)
     "pw_gemm3_reg<20,2>": ("pw_gemm", "hbm", "pw_gemm3_reg_kernel<20, 2, true, false>", lambda K, M, ln, L, mode: K <= 40 and M > 32 and L % 4 == 0 and mode != 1),
     "pw_gemm": ("pw_gemm", "mfma", "pw_gemm* (all variants)", lambda K, M, ln, L, mode: True),
     "gdmlp_fused": ("gdmlp_fused", "mfma", "gdmlp_fused_kernel", None),

@@ -9,7 +9,8 @@ One step = one pass of the hot path over one batch of synthetic input PER RANK:
   -> GT-mean + PSNR per candidate -> per-image selection; for N > 1 the candidates of all ranks are
   all-gathered over RCCL (xGMI) so every rank holds every image's candidates (weak scaling).
 Inputs are resident in HBM before the timed region; weights are seeded random init of the full architecture
-(n_feat 40, blocks [2,2,2], shipped QD model4 decomposition weights).  f32 throughout.
+(n_feat 40, blocks [2,2,2], shipped QD model4 decomposition weights).  f32 tensors throughout; the pointwise GEMMs evaluate
+their f32 products as six bf16-limb products with f32 accumulation (pw_gemm_x6.hip: error below torch's own f32 GEMM).
 """
 import argparse
 import json
@@ -57,7 +58,7 @@ def main():
     ap.add_argument("--samples", type=int, default=8, help="Bayesian samples per image")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-kernel", default="pw_gemm3_reg<20,2>", help="kernel whose launches are timed with HIP events for the roofline entry (bem.ops._KEYS)")
+    ap.add_argument("--profile-kernel", default="pw_x6_stream<2>", help="kernel whose launches are timed with HIP events for the roofline entry (bem.ops._KEYS)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -115,6 +116,7 @@ def main():
             "value": imgs / dt, "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "arithmetic": "f32 storage and accumulation; pointwise GEMM products as exact 3-limb bf16 expansions (6 MFMA products, error <= torch f32 GEMM)",
             "config": {"workload": f"CG_UNet_LOLv1.yml + DecompDualBranch2DDWavelet_4.yml eval, batch={B} {S}x{S}, N={N} Bayesian samples + GT_mean per GPU",
                        "images_per_gpu": B, "samples_per_image": N, "parallelism": f"image-sharded x{world}, RCCL all-gather of candidates"},
         }
