@@ -370,10 +370,10 @@ class SS2D(nn.Module):
 
         def prep():
             xw = self.x_proj_weight.detach()                                # (4, R+2, C)
-            w02 = ops.pack_pw_weight(torch.cat([xw[0], xw[2]], 0).contiguous())
-            w13 = ops.pack_pw_weight(torch.cat([xw[1], xw[3]], 0).contiguous())
+            # one x_proj GEMM over the row-major planes for all four directions: rows [dir 0 | dir 2 | dir 1 | dir 3]
+            wall = ops.pack_pw_weight(torch.cat([xw[0], xw[2], xw[1], xw[3]], 0).contiguous())
             A = (-torch.exp(self.A_logs.detach().float())).reshape(-1).contiguous()
-            return (w02, w13, self.dt_projs_weight.detach().contiguous(), self.dt_projs_bias.detach().contiguous(), A,
+            return (wall, self.dt_projs_weight.detach().contiguous(), self.dt_projs_bias.detach().contiguous(), A,
                     self.Ds.detach().float().contiguous())
         return self._cache.get("scan", [self.x_proj_weight, self.dt_projs_weight, self.dt_projs_bias, self.A_logs, self.Ds], prep)
 
@@ -385,11 +385,13 @@ class SS2D(nn.Module):
         t = ops.pw_gemm(x, Wp, Ci, ln=(norm.weight.detach(), norm.bias.detach()), ln_eps=norm.eps, bias=b)
         w, b = self.conv2d.dw_weights(B)
         xc = ops.dwconv3x3(t, w, b, mode=1)
-        w02, w13, dtw, dtb, A, Ds = self._scan_params()
+        wall, dtw, dtb, A, Ds = self._scan_params()
         xcT = ops.transpose_planes(xc)
-        xd0 = ops.pw_gemm(xc, w02, 2 * (R + 2))
-        xd1 = ops.pw_gemm(xcT, w13, 2 * (R + 2))
-        y0, y1 = ops.ss2d_scan(xc.view(B, Ci, L), xcT.view(B, Ci, L), xd0.view(B, 2, R + 2, L), xd1.view(B, 2, R + 2, L),
+        # x_dbl of the column-major directions = the row-major GEMM's rows in transposed pixel order: 2 (R+2) planes to
+        # transpose instead of a second GEMM pass over the C planes of xcT
+        xd = ops.pw_gemm(xc, wall, 4 * (R + 2))                                   # (B, 4(R+2), H, W)
+        xd1 = ops.transpose_plane_slice(xd, 2 * (R + 2), 2 * (R + 2))             # (B, 2(R+2), W, H)
+        y0, y1 = ops.ss2d_scan(xc.view(B, Ci, L), xcT.view(B, Ci, L), xd.view(B, 4, R + 2, L)[:, :2], xd1.view(B, 2, R + 2, L),
                                dtw, dtb, A, Ds)
         y1r = ops.transpose_planes(y1.view(B, Ci, W, H))
         Wp, b = self.out_proj.gemm_weights(B)

@@ -101,7 +101,8 @@ def cross_merge(ys):
 
 # --------------------------------------------------------------------------- fused SS2D -------
 def ss2d_scan(x0, x1, xd0, xd1, dtw, dtb, A, Ds):
-    for n, t in (("x0", x0), ("x1", x1), ("xd0", xd0), ("xd1", xd1), ("dtw", dtw), ("dtb", dtb), ("A", A), ("Ds", Ds)):
+    """xd0 / xd1 (B,2,R+2,L): contiguous, or channel slices of a wider (B,*,L) buffer (batch stride taken from the view)."""
+    for n, t in (("x0", x0), ("x1", x1), ("dtw", dtw), ("dtb", dtb), ("A", A), ("Ds", Ds)):
         _chk(t, n)
     B, C, L = x0.shape
     R = dtw.shape[2]
@@ -109,11 +110,30 @@ def ss2d_scan(x0, x1, xd0, xd1, dtw, dtb, A, Ds):
         raise ValueError(f"ss2d_scan shapes: x {tuple(x0.shape)}/{tuple(x1.shape)} xd {tuple(xd0.shape)}/{tuple(xd1.shape)} R={R}")
     if dtw.shape != (4, C, R) or dtb.shape != (4, C) or A.numel() != 4 * C or Ds.numel() != 4 * C:
         raise ValueError("ss2d_scan parameter shapes")
+    bs = []
+    for n, t in (("xd0", xd0), ("xd1", xd1)):
+        if not t.is_cuda or t.dtype != torch.float32:
+            raise native.BemNativeError(f"{n} must be a float32 CUDA/HIP tensor")
+        if t.stride()[1:] != ((R + 2) * L, L, 1) or (B > 1 and (t.stride(0) < 2 * (R + 2) * L or t.stride(0) % 4)):
+            raise ValueError(f"{n}: only the batch stride may differ from a contiguous (B,2,R+2,L) tensor")
+        bs.append(t.stride(0) if B > 1 else 0)
     y0 = torch.empty_like(x0)
     y1 = torch.empty_like(x0)
-    check(lib().bem_ss2d_scan_f32(_p(x0), _p(x1), _p(xd0), _p(xd1), _p(dtw), _p(dtb), _p(A), _p(Ds), _p(y0), _p(y1),
-                                  B, C, L, R, _stream()), "ss2d_scan")
+    check(lib().bem_ss2d_scan_strided_f32(_p(x0), _p(x1), _p(xd0), _p(xd1), _p(dtw), _p(dtb), _p(A), _p(Ds), _p(y0), _p(y1),
+                                          B, C, L, R, bs[0], bs[1], _stream()), "ss2d_scan")
     return y0, y1
+
+
+def transpose_plane_slice(x, c0, C):
+    """x (B,Ct,H,W) contiguous -> transposed planes of channels [c0, c0+C): (B,C,W,H) contiguous."""
+    _chk(x, "x")
+    B, Ct, H, W = x.shape
+    if c0 < 0 or c0 + C > Ct or B * C > 65535:
+        raise ValueError("transpose_plane_slice: channel range / plane count")
+    out = torch.empty(B, C, W, H, device=x.device, dtype=x.dtype)
+    check(lib().bem_transpose_planes_f32(ctypes.c_void_p(x.data_ptr() + 4 * c0 * H * W), Ct * H * W, _p(out), C * H * W, B, C, H, W, _stream()),   # (nbatch, planes per batch)
+          "transpose_planes")
+    return out
 
 
 # --------------------------------------------------------------------------- pointwise GEMM ---

@@ -365,7 +365,7 @@ __global__ __launch_bounds__(NT) void ss2d_scan_kernel(
     const float* __restrict__ x0, const float* __restrict__ x1, const float* __restrict__ xd0,
     const float* __restrict__ xd1, const float* __restrict__ dtw, const float* __restrict__ dtb,
     const float* __restrict__ A, const float* __restrict__ Ds, float* __restrict__ y0,
-    float* __restrict__ y1, int Bn, int C, int L, int R) {
+    float* __restrict__ y1, int Bn, int C, int L, int R, int64_t xbs0, int64_t xbs1) {
     __shared__ float agg[2 * (NT / BEM_WAVE)];
     // XCD-aware order: workgroup ids are dealt round-robin to the 8 XCDs, so give each XCD a contiguous range of
     // (orientation, image, channel) work items -- the C channel rows of one (o, b) share its 2*(R+2) x_dbl planes in that XCD's L2.
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(NT) void ss2d_scan_kernel(
     const int wi = xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
     const int c = wi % C, b = (wi / C) % Bn, o = wi / (C * Bn);
     const float* xr = (o ? x1 : x0) + ((int64_t)b * C + c) * L;
-    const float* xd = (o ? xd1 : xd0) + (int64_t)b * 2 * (R + 2) * L;
+    const float* xd = (o ? xd1 + (int64_t)b * xbs1 : xd0 + (int64_t)b * xbs0);
     float* yr = (o ? y1 : y0) + ((int64_t)b * C + c) * L;
     const int kf = o, kr = o + 2;
     const float* wf = dtw + ((int64_t)kf * C + c) * R;
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(NT) void ss2d_scan_full_kernel(
     const float* __restrict__ x0, const float* __restrict__ x1, const float* __restrict__ xd0,
     const float* __restrict__ xd1, const float* __restrict__ dtw, const float* __restrict__ dtb,
     const float* __restrict__ A, const float* __restrict__ Ds, float* __restrict__ y0,
-    float* __restrict__ y1, int Bn, int C, int Rr) {
+    float* __restrict__ y1, int Bn, int C, int Rr, int64_t xbs0, int64_t xbs1) {
     __shared__ float agg[2 * (NT / BEM_WAVE)];
     constexpr int L = NT * E;
     const int R = RT ? RT : Rr;
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(NT) void ss2d_scan_full_kernel(
     const int wi = xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
     const int c = wi % C, b = (wi / C) % Bn, o = wi / (C * Bn);
     const float* xr = (o ? x1 : x0) + ((int64_t)b * C + c) * L;
-    const float* xd = (o ? xd1 : xd0) + (int64_t)b * 2 * (R + 2) * L;
+    const float* xd = (o ? xd1 + (int64_t)b * xbs1 : xd0 + (int64_t)b * xbs0);
     float* yr = (o ? y1 : y0) + ((int64_t)b * C + c) * L;
     const int kf = o, kr = o + 2;
     const int t0 = threadIdx.x * E;
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(NT, MINW) void ss2d_scan_rows_kernel(
     // to (as invariant loads the compiler hoists all CB * T * 2 steps' loads to the top and runs out of registers)
     const float* x0, const float* x1, const float* xd0, const float* xd1, const float* __restrict__ dtw,
     const float* __restrict__ dtb, const float* __restrict__ A, const float* __restrict__ Ds, float* y0, float* y1,
-    int Bn, int C) {
+    int Bn, int C, int64_t xbs0, int64_t xbs1) {
     constexpr int NW = NT / BEM_WAVE, L = NT * 4 * T;
     constexpr int NSLOT = CB > 1 ? CB : 2;
     __shared__ float agg[NSLOT][2 * NW];
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(NT, MINW) void ss2d_scan_rows_kernel(
     const int wi = xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
     const int g = wi % G, b = (wi / G) % Bn, o = wi / (G * Bn);
     const float* xb = (o ? x1 : x0) + (int64_t)b * C * L;
-    const float* xdb = (o ? xd1 : xd0) + (int64_t)b * 2 * (R + 2) * L;
+    const float* xdb = (o ? xd1 + (int64_t)b * xbs1 : xd0 + (int64_t)b * xbs0);
     float* yb = (o ? y1 : y0) + (int64_t)b * C * L;
     const int lane = threadIdx.x & (BEM_WAVE - 1), wave = threadIdx.x / BEM_WAVE;
     float4 y[CB][T];
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(NT) void ss2d_scan_chunks_kernel(
     const float* __restrict__ x0, const float* __restrict__ x1, const float* __restrict__ xd0,
     const float* __restrict__ xd1, const float* __restrict__ dtw, const float* __restrict__ dtb,
     const float* __restrict__ A, const float* __restrict__ Ds, float* __restrict__ y0,
-    float* __restrict__ y1, int Bn, int C, int L, int Rr) {
+    float* __restrict__ y1, int Bn, int C, int L, int Rr, int64_t xbs0, int64_t xbs1) {
     __shared__ float agg[2 * (NT / BEM_WAVE)];
     constexpr int CH = NT * E;
     const int R = RT ? RT : Rr;
@@ -700,7 +700,7 @@ __global__ __launch_bounds__(NT) void ss2d_scan_chunks_kernel(
     const int wi = xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
     const int c = wi % C, b = (wi / C) % Bn, o = wi / (C * Bn);
     const float* xr = (o ? x1 : x0) + ((int64_t)b * C + c) * L;
-    const float* xd = (o ? xd1 : xd0) + (int64_t)b * 2 * (R + 2) * L;
+    const float* xd = (o ? xd1 + (int64_t)b * xbs1 : xd0 + (int64_t)b * xbs0);
     const float* xdr = xd + (int64_t)(R + 2) * L;
     float* yr = (o ? y1 : y0) + ((int64_t)b * C + c) * L;
     const int kf = o, kr = o + 2;
@@ -826,23 +826,35 @@ extern "C" int bem_selective_scan_fwd_f32(const float* u, const float* delta, co
     return bem_check_launch("selective_scan_fwd");
 }
 
+extern "C" int bem_ss2d_scan_strided_f32(const float* x0, const float* x1, const float* xd0, const float* xd1,
+                                         const float* dtw, const float* dtb, const float* A, const float* Ds, float* y0,
+                                         float* y1, int B, int C, int L, int R, int64_t xd0_bstride, int64_t xd1_bstride, void* stream);
+
 extern "C" int bem_ss2d_scan_f32(const float* x0, const float* x1, const float* xd0, const float* xd1,
                                  const float* dtw, const float* dtb, const float* A, const float* Ds, float* y0,
                                  float* y1, int B, int C, int L, int R, void* stream) {
+    return bem_ss2d_scan_strided_f32(x0, x1, xd0, xd1, dtw, dtb, A, Ds, y0, y1, B, C, L, R, 0, 0, stream);
+}
+
+extern "C" int bem_ss2d_scan_strided_f32(const float* x0, const float* x1, const float* xd0, const float* xd1,
+                                         const float* dtw, const float* dtb, const float* A, const float* Ds, float* y0,
+                                         float* y1, int B, int C, int L, int R, int64_t xd0_bstride, int64_t xd1_bstride, void* stream) {
+    const int64_t xbs0 = xd0_bstride ? xd0_bstride : (int64_t)2 * (R + 2) * L, xbs1 = xd1_bstride ? xd1_bstride : (int64_t)2 * (R + 2) * L;
+    BEM_REQUIRE(xbs0 >= (int64_t)2 * (R + 2) * L && xbs1 >= (int64_t)2 * (R + 2) * L && xbs0 % 4 == 0 && xbs1 % 4 == 0, "ss2d_scan: x_dbl batch strides");
     BEM_REQUIRE(x0 && x1 && xd0 && xd1 && dtw && dtb && A && Ds && y0 && y1, "ss2d_scan: null tensor");
     BEM_REQUIRE(B >= 0 && C > 0 && L >= 0 && R >= 1 && (int64_t)B * C * 2 < (1ll << 31), "ss2d_scan: bad shape B=%d C=%d L=%d R=%d", B, C, L, R);
     if (B == 0 || L == 0) return BEM_OK;
     hipStream_t s = (hipStream_t)stream;
     const int grid = C * B * 2;
-#define BEM_SS2D(NT, E) ss2d_scan_kernel<NT, E><<<grid, NT, 0, s>>>(x0, x1, xd0, xd1, dtw, dtb, A, Ds, y0, y1, B, C, L, R)
-#define BEM_SS2D_FULL_R(NT, E, RT) ss2d_scan_full_kernel<NT, E, RT><<<grid, NT, 0, s>>>(x0, x1, xd0, xd1, dtw, dtb, A, Ds, y0, y1, B, C, R)
+#define BEM_SS2D(NT, E) ss2d_scan_kernel<NT, E><<<grid, NT, 0, s>>>(x0, x1, xd0, xd1, dtw, dtb, A, Ds, y0, y1, B, C, L, R, xbs0, xbs1)
+#define BEM_SS2D_FULL_R(NT, E, RT) ss2d_scan_full_kernel<NT, E, RT><<<grid, NT, 0, s>>>(x0, x1, xd0, xd1, dtw, dtb, A, Ds, y0, y1, B, C, R, xbs0, xbs1)
 #define BEM_SS2D_FULL(NT, E) BEM_SS2D_FULL_R(NT, E, 0)      // runtime dt_rank: unrolling its plane loads measured slower (register pressure)
-#define BEM_SS2D_CHUNKS(RT) ss2d_scan_chunks_kernel<256, 8, RT><<<grid, 256, 0, s>>>(x0, x1, xd0, xd1, dtw, dtb, A, Ds, y0, y1, B, C, L, R)
+#define BEM_SS2D_CHUNKS(RT) ss2d_scan_chunks_kernel<256, 8, RT><<<grid, 256, 0, s>>>(x0, x1, xd0, xd1, dtw, dtb, A, Ds, y0, y1, B, C, L, R, xbs0, xbs1)
     const bool al = (((uintptr_t)x0 | (uintptr_t)x1 | (uintptr_t)xd0 | (uintptr_t)xd1 | (uintptr_t)y0 | (uintptr_t)y1) & 15) == 0;
     // channel-blocked whole-row forms for the plane sizes and dt_ranks of a 256x256 image (n_feat 40: C = 40 / 80 / 160)
     static const int variant = getenv("BEM_SCAN_VARIANT") ? atoi(getenv("BEM_SCAN_VARIANT")) : 1;
 #define BEM_SS2D_ROWS(NT, T, CB, RT, MW) do { ss2d_scan_rows_kernel<NT, T, CB, RT, MW><<<((C + CB - 1) / CB) * B * 2, NT, 0, s>>>( \
-        x0, x1, xd0, xd1, dtw, dtb, A, Ds, y0, y1, B, C); return bem_check_launch("ss2d_scan"); } while (0)
+        x0, x1, xd0, xd1, dtw, dtb, A, Ds, y0, y1, B, C, xbs0, xbs1); return bem_check_launch("ss2d_scan"); } while (0)
     if (al && variant) {
         if (L == 1024 && R == 10) { if (variant == 2) BEM_SS2D_ROWS(256, 1, 2, 10, 6); else if (variant == 3) BEM_SS2D_ROWS(256, 1, 4, 10, 4); else BEM_SS2D_ROWS(256, 1, 4, 10, 5); }
         if (L == 4096 && R == 5) {

@@ -74,6 +74,13 @@ int bem_cross_merge_f32(const float* ys, float* y, int B, int C, int H, int W, v
 int bem_ss2d_scan_f32(const float* x0, const float* x1, const float* xd0, const float* xd1,
                       const float* dtw, const float* dtb, const float* A, const float* Ds,
                       float* y0, float* y1, int B, int C, int L, int R, void* stream);
+/* The same with x_dbl tensors that are channel slices of wider buffers: xd*_bstride = elements between batch rows
+ * (0 = contiguous 2*(R+2)*L; multiples of 4).  Lets one x_proj GEMM over the row-major planes produce all four
+ * directions' rows, the {1,3} half being transposed afterwards (10 planes instead of a second pass over C planes). */
+int bem_ss2d_scan_strided_f32(const float* x0, const float* x1, const float* xd0, const float* xd1,
+                              const float* dtw, const float* dtb, const float* A, const float* Ds,
+                              float* y0, float* y1, int B, int C, int L, int R, int64_t xd0_bstride, int64_t xd1_bstride,
+                              void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Pointwise (1x1) channel-mix GEMM on f32 MFMA with fused prologue / epilogue.  Replaces

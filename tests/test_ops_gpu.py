@@ -481,3 +481,22 @@ def test_pw_gemm_x6_accuracy(ops, cfg):
     e32 = (r32.double() - r64).abs().mean().item()
     assert d.abs().mean().item() <= e32, (d.abs().mean().item(), e32)
     assert abs(d.mean().item()) < 0.1 * e32, ("bias", d.mean().item(), e32)
+
+
+def test_transpose_plane_slice_and_strided_scan_inputs(ops):
+    """transpose of a channel slice (batch-strided source) and bem_ss2d_scan_strided: x_dbl given as channel slices of a
+    wider buffer must give the same result as contiguous copies."""
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(3, 7, 5, 9, generator=g)
+    t = ops.transpose_plane_slice(dev(x), 2, 4)
+    assert torch.equal(t.cpu(), x[:, 2:6].transpose(2, 3).contiguous())
+    B, C, H, W, R = 2, 8, 16, 16, 3
+    L = H * W
+    x0, x1 = torch.randn(B, C, L, generator=g), torch.randn(B, C, L, generator=g)
+    wide = torch.randn(B, 4, R + 2, L, generator=g)
+    dtw, dtb = torch.randn(4, C, R, generator=g) * 0.3, torch.randn(4, C, generator=g) - 2
+    A, Ds = -torch.rand(4 * C, generator=g), torch.randn(4 * C, generator=g)
+    wd = dev(wide)
+    a = ops.ss2d_scan(dev(x0), dev(x1), wd[:, :2], wd[:, 2:], dev(dtw), dev(dtb), dev(A), dev(Ds))
+    b = ops.ss2d_scan(dev(x0), dev(x1), wd[:, :2].contiguous(), wd[:, 2:].contiguous(), dev(dtw), dev(dtb), dev(A), dev(Ds))
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
