@@ -875,7 +875,9 @@ extern "C" int bem_ss2d_scan_strided_f32(const float* x0, const float* x1, const
         if (L == 1024 && R == 10) { if (variant == 2) BEM_SS2D_ROWS(256, 1, 2, 10, 6); else if (variant == 3) BEM_SS2D_ROWS(256, 1, 4, 10, 4); else BEM_SS2D_ROWS(256, 1, 4, 10, 5); }
         if (L == 4096 && R == 5) {
             if (variant == 2) BEM_SS2D_ROWS(512, 2, 4, 5, 4); else if (variant == 3) BEM_SS2D_ROWS(256, 4, 2, 5, 5);
-            else if (variant == 4) BEM_SS2D_ROWS(1024, 1, 4, 5, 4); else BEM_SS2D_ROWS(256, 4, 4, 5, 4);
+            else if (variant == 4) BEM_SS2D_ROWS(1024, 1, 4, 5, 4); else if (variant == 5) BEM_SS2D_ROWS(1024, 1, 1, 5, 8);
+            else if (variant == 6) BEM_SS2D_ROWS(1024, 1, 2, 5, 6); else if (variant == 7) BEM_SS2D_ROWS(256, 4, 4, 5, 4);
+            else BEM_SS2D_ROWS(512, 2, 2, 5, 6);       // measured best of the sweep (139 us; 256 x 4 tiles x 4 channels: 157)
         }
         if (L == 16384 && R == 3) {
             if (variant == 2) BEM_SS2D_ROWS(1024, 4, 2, 3, 4); else if (variant == 3) BEM_SS2D_ROWS(512, 8, 2, 3, 4);
