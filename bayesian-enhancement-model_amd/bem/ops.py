@@ -317,6 +317,22 @@ def _packed_conv_weight(w):
     return hit[1]
 
 
+_CONV_PACK_X6 = {}       # same keys -> (9 taps, x6-packed (Cout, Cin)) weights for the shifted-tap 3x3 convolution
+USE_CONV_X6 = __import__("os").environ.get("BEM_CONV_X6", "1") != "0"
+
+
+def _packed_conv_weight_x6(w):
+    key = (w.data_ptr(), w._version, tuple(w.shape))
+    hit = _CONV_PACK_X6.get(key)
+    if hit is None:
+        if len(_CONV_PACK_X6) > 256:
+            _CONV_PACK_X6.clear()
+        taps = w.permute(2, 3, 0, 1).reshape(9, w.shape[0], w.shape[1]).contiguous()       # tap = ky * 3 + kx
+        hit = (w, pack_pw_weight(taps, x6=True))
+        _CONV_PACK_X6[key] = hit
+    return hit[1]
+
+
 def conv2d(x, w, bias=None, stride=1, pad=1, relu=False, res1=None, res2=None, cin_slice=None):
     """Dense conv.  ``cin_slice=(c0, Cin)`` convolves channels [c0, c0+Cin) of a wider contiguous x.
     Runs as an implicit GEMM on the matrix cores (Cout <= 160), else on the direct VALU kernel."""
@@ -339,6 +355,11 @@ def conv2d(x, w, bias=None, stride=1, pad=1, relu=False, res1=None, res2=None, c
     if bias is not None and bias.shape != (Cout,):
         raise ValueError("conv2d: bias shape")
     xp = ctypes.c_void_p(x.data_ptr() + 4 * c0 * H * W)
+    if USE_CONV_X6 and USE_X6 and (KH, KW, stride, pad) == (3, 3, 1, 1) and W % 2 == 0 and Cin % 8 == 0 and (c0 * H * W) % 2 == 0:
+        # nine shifted 1x1 taps on the bf16-limb GEMM machinery (pw_gemm_x6.hip)
+        check(lib().bem_conv3x3_x6_f32(xp, Ct * H * W, _p(_packed_conv_weight_x6(w)), _p(bias), _p(res1), _p(res2), _p(out), B, Cin, H, W,
+                                       Cout, int(relu), _stream()), "conv3x3_x6")
+        return out
     if USE_CONV_MFMA and Cout <= 160 and ((KH, KW, stride) in ((3, 3, 1), (4, 4, 2))):
         check(lib().bem_conv2d_mfma_f32(xp, Ct * H * W, _p(_packed_conv_weight(w)), _p(bias), _p(res1), _p(res2), _p(out), B, Cin, H, W,
                                         Cout, KH, KW, stride, pad, int(relu), _stream()), "conv2d_mfma")

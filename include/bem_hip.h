@@ -165,6 +165,12 @@ int bem_conv2d_mfma_f32(const float* x, int64_t x_bstride, const float* Wp, cons
                         const float* res2, float* out, int B, int Cin, int H, int W, int Cout, int KH, int KW,
                         int stride, int pad, int relu, void* stream);
 
+/* The 3x3 stride-1 pad-1 case as nine shifted 1x1 taps on the bf16-limb GEMM (see bem_pw_gemm_x6_f32): no im2col patch,
+ * f32-level error.  Wp = bem_pack_pw_weight_x6 of the (9, Cout, Cin) tap matrices, tap = ky*3 + kx (nsets = 9).
+ * W even, Cin % 8 == 0; x_bstride as above; out = relu?(conv + bias) + res1 + res2. */
+int bem_conv3x3_x6_f32(const float* x, int64_t x_bstride, const float* Wp, const float* bias, const float* res1,
+                       const float* res2, float* out, int B, int Cin, int H, int W, int Cout, int relu, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Quaternion / Haar primitives (basicsr/QD/model4.py:7-37,216-232; QD/quaternion.py:3-17).
  * ------------------------------------------------------------------------------------------- */

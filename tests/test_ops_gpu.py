@@ -235,6 +235,27 @@ def test_conv2d(ops, cfg):
               F.conv2d(x[:, 2:5], w[:, 2:5], None, stride=s, padding=1), 1e-4, 2e-5, "conv channel slice")
 
 
+@pytest.mark.parametrize("cfg", [(2, 32, 32, 16, 16, True), (1, 40, 16, 9, 14, False), (2, 8, 40, 33, 6, True), (1, 24, 80, 8, 130, False), (1, 32, 32, 128, 128, True)])
+def test_conv3x3_x6_taps(ops, cfg):
+    """3x3 convolution as nine shifted bf16-limb GEMM taps (bem_conv3x3_x6_f32): borders, half-filled last k-block (Cin % 16 == 8),
+    1 / 2 / 3 M-tiles, relu + two residuals, channel-slice input; against F.conv2d in float64 with the f32 run as the yardstick."""
+    B, Ci, Co, H, W, relu = cfg
+    g = torch.Generator().manual_seed(Ci + Co + H)
+    x, w, b = torch.randn(B, Ci, H, W, generator=g), torch.randn(Co, Ci, 3, 3, generator=g) * (Ci * 9) ** -0.5, torch.randn(Co, generator=g)
+    r1, r2 = torch.randn(B, Co, H, W, generator=g), torch.randn(B, Co, H, W, generator=g)
+    def run(dt):
+        y = F.conv2d(x.to(dt), w.to(dt), b.to(dt), padding=1)
+        return (F.relu(y) if relu else y) + r1.to(dt) + r2.to(dt)
+    r64, r32 = run(torch.float64), run(torch.float32)
+    y = ops.conv2d(dev(x), dev(w), dev(b), stride=1, pad=1, relu=relu, res1=dev(r1), res2=dev(r2))
+    close(y, r32, 1e-4, 2e-5, f"conv3x3 x6 {cfg}")
+    e32 = (r32.double() - r64).abs().mean().item()
+    assert (y.cpu().double() - r64).abs().mean().item() <= 1.2 * e32 + 1e-9
+    wide = torch.randn(B, Ci + 6, H, W, generator=g)
+    ys = ops.conv2d(dev(wide), dev(w), None, stride=1, pad=1, cin_slice=(4, Ci))
+    close(ys, F.conv2d(wide[:, 4:4 + Ci], w, None, padding=1), 1e-4, 2e-5, "conv3x3 x6 channel slice")
+
+
 # ----------------------------------------------------------------------------- Haar / quaternion -
 def test_haar_quaternion_golden(ops):
     g = load_golden("g3_haar")
