@@ -24,6 +24,7 @@
 //     "stream" kernel (no LayerNorm, any K): x is streamed k-block by k-block, one block ahead of the MFMAs.
 #include "bem_common.h"
 #include <stdlib.h>
+#include <algorithm>
 
 namespace {
 
@@ -39,6 +40,7 @@ struct PwX {
     const float* res; const float* prelu; int act;
     float* out; int out_mode; int Win;
     int M; int K; int L; int KB; int MT;
+    int mtpb;      // resident kernel: M-tiles per workgroup (grid.y slices M when there are too few pixels to fill the GPU)
 };
 
 __device__ __forceinline__ uint32_t fbits(float v) { return __builtin_bit_cast(uint32_t, v); }
@@ -386,8 +388,9 @@ __global__ __launch_bounds__(256, 2) void pw_x6_res_kernel(PwX k) {
         }
     };
     u32x4 wn[MTW][3];
-    load_w(0, 0, wn);
-    for (int mt0 = 0; mt0 < k.MT; mt0 += MTW) {
+    const int mt_lo = blockIdx.y * k.mtpb, mt_hi = min(k.MT, mt_lo + k.mtpb);
+    load_w(mt_lo, 0, wn);
+    for (int mt0 = mt_lo; mt0 < mt_hi; mt0 += MTW) {
         f32x16 acc[MTW][NSUB], alo[MTW][NSUB];
         float4 bq[MTW][4];
         x6_load_bias<MTW>(k, b, mt0, kh, bq);
@@ -594,7 +597,7 @@ extern "C" int bem_pw_gemm_x6_f32(const bem_pw_args* a, void* stream) {
     k.ln_w = a->ln_w; k.ln_b = a->ln_b; k.ln_eps = a->ln_eps;
     k.Wp = reinterpret_cast<const u32x4*>(a->Wp); k.w_bstride = a->w_bstride / 4; k.bias = a->bias; k.bias_bstride = a->bias_bstride;
     k.res = a->res; k.prelu = a->prelu; k.act = a->act; k.out = a->out; k.out_mode = a->out_mode; k.Win = a->Win;
-    k.M = a->M; k.K = a->K; k.L = a->L; k.KB = cdiv(a->K, 16); k.MT = cdiv(a->M, 32);
+    k.M = a->M; k.K = a->K; k.L = a->L; k.KB = cdiv(a->K, 16); k.MT = cdiv(a->M, 32); k.mtpb = k.MT;
     hipStream_t s = (hipStream_t)stream;
     const bool sum = a->in_mode == 1;
     const bool al = (((uintptr_t)a->x1 | (uintptr_t)(a->x2 ? a->x2 : a->x1) | (uintptr_t)a->out | (uintptr_t)(a->res ? a->res : a->out)) & 7) == 0;
@@ -602,6 +605,13 @@ extern "C" int bem_pw_gemm_x6_f32(const bem_pw_args* a, void* stream) {
 #define BEM_X6_RES(KBM, NSUB, MTW)                                                                       \
     do {                                                                                                 \
         dim3 grid(cdiv(a->L, 128 * NSUB), 1, a->B);                                                      \
+        /* few pixels (Stage I: 4x4 ... 16x16 maps), many output rows: slice M over grid.y so that the weight stream of  \
+           one sample is pulled by several workgroups (each repeats the cheap LayerNorm of the same pixels) */            \
+        const int64_t wv = (int64_t)a->B * cdiv(a->L, 32 * NSUB);                                        \
+        const int groups = cdiv(k.MT, MTW);                                                              \
+        const int ny = wv >= 2048 ? 1 : (int)std::min<int64_t>(groups, cdiv64(2048, wv));                \
+        k.mtpb = cdiv(groups, ny) * MTW;                                                                 \
+        grid.y = cdiv(k.MT, k.mtpb);                                                                     \
         if (NSUB == 2 && vec && !sum) pw_x6_res_kernel<KBM, NSUB, MTW, false, true><<<grid, 256, 0, s>>>(k);   \
         else if (NSUB == 2 && vec) pw_x6_res_kernel<KBM, NSUB, MTW, true, true><<<grid, 256, 0, s>>>(k);       \
         else if (!sum) pw_x6_res_kernel<KBM, NSUB, MTW, false, false><<<grid, 256, 0, s>>>(k);                 \
