@@ -319,6 +319,8 @@ def _packed_conv_weight(w):
 
 _CONV_PACK_X6 = {}       # same keys -> (9 taps, x6-packed (Cout, Cin)) weights for the shifted-tap 3x3 convolution
 USE_CONV_X6 = __import__("os").environ.get("BEM_CONV_X6", "1") != "0"
+# the 16-tap form of the 4x4 stride-2 convolution measured no faster than the f32-MFMA im2col kernel (504 vs 537 us at 40 -> 80): off by default
+USE_CONV4_X6 = __import__("os").environ.get("BEM_CONV4_X6", "0") != "0"
 
 
 def _packed_conv_weight_x6(w):
@@ -327,7 +329,7 @@ def _packed_conv_weight_x6(w):
     if hit is None:
         if len(_CONV_PACK_X6) > 256:
             _CONV_PACK_X6.clear()
-        taps = w.permute(2, 3, 0, 1).reshape(9, w.shape[0], w.shape[1]).contiguous()       # tap = ky * 3 + kx
+        taps = w.permute(2, 3, 0, 1).reshape(w.shape[2] * w.shape[3], w.shape[0], w.shape[1]).contiguous()       # tap = ky * KW + kx
         hit = (w, pack_pw_weight(taps, x6=True))
         _CONV_PACK_X6[key] = hit
     return hit[1]
@@ -359,6 +361,10 @@ def conv2d(x, w, bias=None, stride=1, pad=1, relu=False, res1=None, res2=None, c
         # nine shifted 1x1 taps on the bf16-limb GEMM machinery (pw_gemm_x6.hip)
         check(lib().bem_conv3x3_x6_f32(xp, Ct * H * W, _p(_packed_conv_weight_x6(w)), _p(bias), _p(res1), _p(res2), _p(out), B, Cin, H, W,
                                        Cout, int(relu), _stream()), "conv3x3_x6")
+        return out
+    if USE_CONV4_X6 and USE_X6 and (KH, KW, stride, pad) == (4, 4, 2, 1) and Wo % 2 == 0 and Cin % 8 == 0 and (c0 * H * W) % 2 == 0:
+        check(lib().bem_conv4x4s2_x6_f32(xp, Ct * H * W, _p(_packed_conv_weight_x6(w)), _p(bias), _p(res1), _p(res2), _p(out), B, Cin, H, W,
+                                         Cout, int(relu), _stream()), "conv4x4s2_x6")
         return out
     if USE_CONV_MFMA and Cout <= 160 and ((KH, KW, stride) in ((3, 3, 1), (4, 4, 2))):
         check(lib().bem_conv2d_mfma_f32(xp, Ct * H * W, _p(_packed_conv_weight(w)), _p(bias), _p(res1), _p(res2), _p(out), B, Cin, H, W,

@@ -641,34 +641,35 @@ extern "C" int bem_pw_gemm_x6_f32(const bem_pw_args* a, void* stream) {
 }
 
 // ================================================================================================
-// Dense 3x3 convolution (stride 1, zero padding 1) as nine shifted 1x1 GEMM taps on the same x6 machinery:
-//     out[co][p] = relu?( sum_{tap} sum_ci W[co][ci][tap] * x[ci][p + tap offset] + bias[co] ) + res1 + res2
-// No im2col patch: tap (dy, dx) reads the wave's 64 pixels displaced by dy rows and dx columns straight from global
-// memory (the nine displaced reads of a k-block overlap and are served by L1 / L2), masks the pixels that fall outside
-// the image, splits them into bf16 limbs and issues the six limb products against that tap's weight block.  The x loads of
-// the next tap are requested before the MFMAs of the current one.  Wp: (9 taps, MT, KB, 3 limbs, 64 lanes) 16-byte vectors =
-// bem_pack_pw_weight_x6 of the (9, Cout, Cin) tap matrices.  Requires W even and Cin % 8 == 0.
+// Dense convolutions as shifted 1x1 GEMM taps on the same x6 machinery (3x3 stride 1 pad 1; 4x4 stride 2 pad 1):
+//     out[co][p] = relu?( sum_{tap} sum_ci W[co][ci][tap] * x[ci][S*p + tap offset] + bias[co] ) + res1 + res2
+// No im2col patch: tap (ky, kx) reads the input pixels of the wave's 64 output pixels straight from global memory (the
+// displaced reads of a k-block overlap and are served by L1 / L2), masks the pixels that fall outside the image, splits
+// them into bf16 limbs and issues the six limb products against that tap's weight block.  The x loads of the next tap
+// are requested before the MFMAs of the current one.  Wp: (KH*KW taps, MT, KB, 3 limbs, 64 lanes) 16-byte vectors =
+// bem_pack_pw_weight_x6 of the (KH*KW, Cout, Cin) tap matrices.  Requires an even output width and Cin % 8 == 0.
 // ================================================================================================
 namespace {
 
 struct CvX {
     const float* x; int64_t x_bs;
     const u32x4* Wp; const float* bias; const float* res1; const float* res2; float* out;
-    int Cin, H, W, Cout, KB, MT, relu;
+    int Cin, H, W, Ho, Wo, Cout, KB, MT, relu, pad;
 };
 
-template <int MTW>
-__global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(CvX k) {
-    constexpr int NSUB = 2;
+template <int MTW, int KH, int KW, int S>
+__global__ __launch_bounds__(256, 2) void conv_taps_x6_kernel(CvX k) {
+    constexpr int NSUB = 2, NTAP = KH * KW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kh = lane >> 5, n = lane & 31;
     const int b = blockIdx.z, mt0 = blockIdx.y * MTW;
-    const int L = k.H * k.W;
+    const int Lo = k.Ho * k.Wo, Li = k.H * k.W;
     const int p0 = (xcd_tile(blockIdx.x, gridDim.x) * 4 + wave) * 64;
-    if (p0 >= L) return;
-    const int p = p0 + 2 * n;                       // this lane's two pixels p, p + 1 (same row: W is even)
-    const bool live = p < L;
+    if (p0 >= Lo) return;
+    const int p = p0 + 2 * n;                       // this lane's two output pixels p, p + 1 (same row: Wo is even)
+    const bool live = p < Lo;
     const int pc = live ? p : 0;
-    const int y = pc / k.W, x = pc - y * k.W;
+    const int yo = pc / k.Wo, xo = pc - yo * k.Wo;
+    const int yi0 = yo * S - k.pad, xi0 = xo * S - k.pad;      // input position of tap (0, 0) for the first pixel
     const float* xb = k.x + (int64_t)b * k.x_bs;
     f32x16 acc[MTW][NSUB], alo[MTW][NSUB];
 #pragma unroll
@@ -679,32 +680,43 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(CvX k) {
             for (int r = 0; r < 16; ++r) acc[m][t][r] = alo[m][t][r] = 0.f;
     const u32x4* wbase = k.Wp + lane;
     const int64_t tap_stride = (int64_t)k.MT * k.KB * 3 * 64, mt_stride = (int64_t)k.KB * 3 * 64;
-    const int nsteps = k.KB * 9;
-    // step s = kb * 9 + tap.  Loads of a step: 8 channels (16 kb + 8 kh + e) at the displaced pixel pair.
+    const int nsteps = k.KB * NTAP;
+    // step s = kb * NTAP + tap.  Loads of a step: 8 channels (16 kb + 8 kh + e) at the two input pixels of this tap.
     auto load_x = [&](int s, float (&dst)[8][NSUB], float (&mk)[NSUB]) {
-        const int kb = min(s / 9, k.KB - 1), tap = s - (s / 9) * 9;
-        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        const int yy = y + dy;
+        const int kb = min(s / NTAP, k.KB - 1), tap = s - (s / NTAP) * NTAP;
+        const int ky = tap / KW, kx = tap - ky * KW;
+        const int yy = yi0 + ky, x0 = xi0 + kx, x1 = x0 + S;
         const bool rowok = live && yy >= 0 && yy < k.H;
-        mk[0] = (rowok && x + dx >= 0 && x + dx < k.W) ? 1.f : 0.f;
-        mk[1] = (rowok && x + 1 + dx >= 0 && x + 1 + dx < k.W) ? 1.f : 0.f;
-        // the displaced pair (q, q + 1) as ONE 8-byte load (global loads need dword alignment only) at a base clamped into
-        // the plane; d = q - base is 0 except at the two ends of the plane, where one of the two pixels is outside anyway
-        const int q = pc + dy * k.W + dx, qb = min(max(q, 0), L - 2), d = q - qb;
+        mk[0] = (rowok && x0 >= 0 && x0 < k.W) ? 1.f : 0.f;
+        mk[1] = (rowok && x1 >= 0 && x1 < k.W) ? 1.f : 0.f;
+        const int q = yy * k.W + x0;
         // the upper half-wave reads channels + 8; past Cin (a half-filled last k-block) it re-reads the lower half,
         // whose weights there are zero
         const int c0 = 16 * kb, hoff = (c0 + 8 < k.Cin) ? 8 * kh : 0;
+        if (S == 1) {
+            // the pair (q, q + 1) as ONE 8-byte load (global loads need dword alignment only) at a base clamped into the
+            // plane; d = q - base is 0 except at the two ends of the plane, where one of the two pixels is outside anyway
+            const int qb = min(max(q, 0), Li - 2), d = q - qb;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float* pl = xb + (int64_t)(min(c0 + e, k.Cin - 1 - hoff) + hoff) * L;
-            float2 v;
-            __builtin_memcpy(&v, pl + qb, sizeof(v));       // 4-byte aligned 8-byte load
-            dst[e][0] = d > 0 ? v.y : v.x;                  // d = +1: wanted (L-1, L): first = v.y
-            dst[e][1] = d < 0 ? v.x : v.y;                  // d = -1: wanted (-1, 0): second = v.x
+            for (int e = 0; e < 8; ++e) {
+                const float* pl = xb + (int64_t)(min(c0 + e, k.Cin - 1 - hoff) + hoff) * Li;
+                float2 v;
+                __builtin_memcpy(&v, pl + qb, sizeof(v));
+                dst[e][0] = d > 0 ? v.y : v.x;
+                dst[e][1] = d < 0 ? v.x : v.y;
+            }
+        } else {
+            const int q0 = min(max(q, 0), Li - 1), q1 = min(max(q + S, 0), Li - 1);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float* pl = xb + (int64_t)(min(c0 + e, k.Cin - 1 - hoff) + hoff) * Li;
+                dst[e][0] = pl[q0];
+                dst[e][1] = pl[q1];
+            }
         }
     };
     auto load_w = [&](int s, u32x4 (&dst)[MTW][3]) {
-        const int sc = min(s, nsteps - 1), kb = sc / 9, tap = sc - kb * 9;
+        const int sc = min(s, nsteps - 1), kb = sc / NTAP, tap = sc - kb * NTAP;
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
             const bool ok = s < nsteps && mt0 + m < k.MT;
@@ -743,10 +755,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(CvX k) {
     }
     // epilogue: out = relu?(acc + bias) + res1 + res2, plane bases uniform, one lane offset
     const float lo = k.relu ? 0.f : -3.402823466e38f;
-    const uint32_t loff = (uint32_t)(4 * kh) * (uint32_t)L + (uint32_t)pc;
-    float* outb = k.out + (int64_t)b * k.Cout * L;
-    const float* r1b = k.res1 ? k.res1 + (int64_t)b * k.Cout * L : nullptr;
-    const float* r2b = k.res2 ? k.res2 + (int64_t)b * k.Cout * L : nullptr;
+    const uint32_t loff = (uint32_t)(4 * kh) * (uint32_t)Lo + (uint32_t)pc;
+    float* outb = k.out + (int64_t)b * k.Cout * Lo;
+    const float* r1b = k.res1 ? k.res1 + (int64_t)b * k.Cout * Lo : nullptr;
+    const float* r2b = k.res2 ? k.res2 + (int64_t)b * k.Cout * Lo : nullptr;
 #pragma unroll
     for (int m = 0; m < MTW; ++m) {
         if (mt0 + m >= k.MT) continue;
@@ -760,7 +772,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(CvX k) {
                 const int lrow = min(urow + 4 * kh, k.Cout - 1);
                 bv[i] = k.bias ? k.bias[lrow] : 0.f;
                 rv[i][0] = rv[i][1] = 0.f;
-                const uint32_t ro = (uint32_t)lrow * (uint32_t)L + (uint32_t)pc;
+                const uint32_t ro = (uint32_t)lrow * (uint32_t)Lo + (uint32_t)pc;
                 if (r1b) { const float2 q = *reinterpret_cast<const float2*>(r1b + ro); rv[i][0] += q.x; rv[i][1] += q.y; }
                 if (r2b) { const float2 q = *reinterpret_cast<const float2*>(r2b + ro); rv[i][0] += q.x; rv[i][1] += q.y; }
             }
@@ -769,7 +781,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(CvX k) {
                 const int r = 4 * g + i, urow = rb + 8 * g + i;
                 const float o0 = fmaxf(acc[m][0][r] + alo[m][0][r] + bv[i], lo) + rv[i][0];
                 const float o1 = fmaxf(acc[m][1][r] + alo[m][1][r] + bv[i], lo) + rv[i][1];
-                if (live && urow + 4 * kh < k.Cout) *reinterpret_cast<float2*>(outb + (int64_t)urow * L + loff) = make_float2(o0, o1);
+                if (live && urow + 4 * kh < k.Cout) *reinterpret_cast<float2*>(outb + (int64_t)urow * Lo + loff) = make_float2(o0, o1);
             }
         }
     }
@@ -777,21 +789,38 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(CvX k) {
 
 }  // namespace
 
-extern "C" int bem_conv3x3_x6_f32(const float* x, int64_t x_bstride, const float* Wp, const float* bias, const float* res1,
-                                  const float* res2, float* out, int B, int Cin, int H, int W, int Cout, int relu, void* stream) {
-    BEM_REQUIRE(x && Wp && out, "conv3x3_x6: null tensor");
-    BEM_REQUIRE(B >= 0 && B <= 65535 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "conv3x3_x6: bad shape");
-    BEM_REQUIRE(W % 2 == 0 && Cin % 8 == 0, "conv3x3_x6: needs an even width and Cin %% 8 == 0 (got W=%d Cin=%d)", W, Cin);
+static int conv_taps_launch(const float* x, int64_t x_bstride, const float* Wp, const float* bias, const float* res1, const float* res2,
+                            float* out, int B, int Cin, int H, int W, int Cout, int KH, int stride, int relu, void* stream, const char* what) {
+    BEM_REQUIRE(x && Wp && out, "%s: null tensor", what);
+    BEM_REQUIRE(B >= 0 && B <= 65535 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "%s: bad shape", what);
+    const int Ho = (H + 2 - KH) / stride + 1, Wo = (W + 2 - KH) / stride + 1;
+    BEM_REQUIRE(Ho > 0 && Wo > 0 && Wo % 2 == 0 && Cin % 8 == 0 && H * W >= 2, "%s: needs an even output width and Cin %% 8 == 0 (got Wo=%d Cin=%d)", what, Wo, Cin);
     BEM_REQUIRE(((uintptr_t)Wp & 15) == 0 && (((uintptr_t)out | (uintptr_t)(res1 ? res1 : out) | (uintptr_t)(res2 ? res2 : out)) & 7) == 0,
-                "conv3x3_x6: alignment (packed weights 16 bytes, out / residuals 8 bytes)");
-    BEM_REQUIRE((int64_t)Cout * H * W < (1ll << 30) && (int64_t)Cin * H * W < (1ll << 30), "conv3x3_x6: plane set too large for 32-bit lane offsets");
+                "%s: alignment (packed weights 16 bytes, out / residuals 8 bytes)", what);
+    BEM_REQUIRE((int64_t)Cout * Ho * Wo < (1ll << 30) && (int64_t)Cin * H * W < (1ll << 30), "%s: plane set too large for 32-bit lane offsets", what);
     if (B == 0) return BEM_OK;
     CvX k;
     k.x = x; k.x_bs = x_bstride; k.Wp = reinterpret_cast<const u32x4*>(Wp); k.bias = bias; k.res1 = res1; k.res2 = res2; k.out = out;
-    k.Cin = Cin; k.H = H; k.W = W; k.Cout = Cout; k.KB = cdiv(Cin, 16); k.MT = cdiv(Cout, 32); k.relu = relu;
+    k.Cin = Cin; k.H = H; k.W = W; k.Ho = Ho; k.Wo = Wo; k.Cout = Cout; k.KB = cdiv(Cin, 16); k.MT = cdiv(Cout, 32); k.relu = relu; k.pad = 1;
     const int mtw = k.MT == 1 ? 1 : 2;
-    dim3 grid(cdiv(H * W, 256), cdiv(k.MT, mtw), B);
-    if (mtw == 1) conv3x3_x6_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(k);
-    else conv3x3_x6_kernel<2><<<grid, 256, 0, (hipStream_t)stream>>>(k);
-    return bem_check_launch("conv3x3_x6");
+    dim3 grid(cdiv(Ho * Wo, 256), cdiv(k.MT, mtw), B);
+    hipStream_t s = (hipStream_t)stream;
+    if (KH == 3) {
+        if (mtw == 1) conv_taps_x6_kernel<1, 3, 3, 1><<<grid, 256, 0, s>>>(k);
+        else conv_taps_x6_kernel<2, 3, 3, 1><<<grid, 256, 0, s>>>(k);
+    } else {
+        if (mtw == 1) conv_taps_x6_kernel<1, 4, 4, 2><<<grid, 256, 0, s>>>(k);
+        else conv_taps_x6_kernel<2, 4, 4, 2><<<grid, 256, 0, s>>>(k);
+    }
+    return bem_check_launch(what);
+}
+
+extern "C" int bem_conv3x3_x6_f32(const float* x, int64_t x_bstride, const float* Wp, const float* bias, const float* res1,
+                                  const float* res2, float* out, int B, int Cin, int H, int W, int Cout, int relu, void* stream) {
+    return conv_taps_launch(x, x_bstride, Wp, bias, res1, res2, out, B, Cin, H, W, Cout, 3, 1, relu, stream, "conv3x3_x6");
+}
+
+extern "C" int bem_conv4x4s2_x6_f32(const float* x, int64_t x_bstride, const float* Wp, const float* bias, const float* res1,
+                                    const float* res2, float* out, int B, int Cin, int H, int W, int Cout, int relu, void* stream) {
+    return conv_taps_launch(x, x_bstride, Wp, bias, res1, res2, out, B, Cin, H, W, Cout, 4, 2, relu, stream, "conv4x4s2_x6");
 }

@@ -170,6 +170,9 @@ int bem_conv2d_mfma_f32(const float* x, int64_t x_bstride, const float* Wp, cons
  * W even, Cin % 8 == 0; x_bstride as above; out = relu?(conv + bias) + res1 + res2. */
 int bem_conv3x3_x6_f32(const float* x, int64_t x_bstride, const float* Wp, const float* bias, const float* res1,
                        const float* res2, float* out, int B, int Cin, int H, int W, int Cout, int relu, void* stream);
+/* The 4x4 stride-2 pad-1 down-sampling convolution the same way (16 taps, tap = ky*4 + kx); even output width, Cin % 8 == 0. */
+int bem_conv4x4s2_x6_f32(const float* x, int64_t x_bstride, const float* Wp, const float* bias, const float* res1,
+                         const float* res2, float* out, int B, int Cin, int H, int W, int Cout, int relu, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Quaternion / Haar primitives (basicsr/QD/model4.py:7-37,216-232; QD/quaternion.py:3-17).

@@ -221,9 +221,12 @@ def test_dwconv_modes(ops, cfg):
 
 
 @pytest.mark.parametrize("cfg", [(2, 32, 32, 16, 20, 3, 1), (1, 11, 40, 9, 33, 3, 1), (1, 40, 16, 8, 8, 3, 1), (2, 40, 80, 16, 12, 4, 2),
-                                 (1, 3, 40, 5, 7, 3, 1), (1, 80, 160, 6, 10, 4, 2), (1, 40, 3, 70, 40, 3, 1)])
-def test_conv2d(ops, cfg):
+                                 (1, 3, 40, 5, 7, 3, 1), (1, 80, 160, 6, 10, 4, 2), (1, 40, 3, 70, 40, 3, 1),
+                                 (1, 40, 80, 32, 64, 4, 2), (2, 80, 160, 16, 16, 4, 2), (1, 8, 24, 6, 4, 4, 2)])   # 4x4-s2 as 16 x6 taps
+def test_conv2d(ops, cfg, monkeypatch):
     B, Ci, Co, H, W, k, s = cfg
+    if k == 4 and Ci % 8 == 0 and H * W > 100:
+        monkeypatch.setattr(ops, "USE_CONV4_X6", True)         # also exercise the (default-off) 16-tap x6 form
     g = torch.Generator().manual_seed(Ci * Co)
     x, w, b = torch.randn(B, Ci, H, W, generator=g), torch.randn(Co, Ci, k, k, generator=g) * (Ci * k * k) ** -0.5, torch.randn(Co, generator=g)
     ref = F.conv2d(x, w, b, stride=s, padding=1)
