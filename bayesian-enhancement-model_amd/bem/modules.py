@@ -194,8 +194,9 @@ class _BayesBase(nn.Module):
     def _rho_init(self):
         return math.log(math.expm1(abs(self.sigma_init)) + 1e-20)
 
-    def _sampled(self, B):
-        """(weights (nsets,*shape), bias (nsets,C)|None, nsets) for this forward."""
+    def _sampled(self, B, packed_mk=None):
+        """(weights (nsets,*shape), bias (nsets,C)|None, nsets) for this forward; with ``packed_mk = (M, K)`` the sampled
+        weights come back already packed for the x6 GEMM (stochastic mode only)."""
         ctx = _SAMPLE_CTX[0]
         if self.deterministic:
             return self.mu_weight.detach()[None], (self.mu_bias.detach()[None] if self.bias else None), 1
@@ -209,7 +210,11 @@ class _BayesBase(nn.Module):
             ew = ctx.eps[self.module_path + ".weight"].contiguous()
             if self.bias:
                 eb = ctx.eps[self.module_path + ".bias"].contiguous()
-        w = ops.bnn_sample(self.mu_weight.detach(), self.rho_weight.detach(), ns, ew, ctx.seed, ctx.next_stream())
+        if packed_mk is not None and ops.USE_X6:
+            # GEMM weights go straight into operand order (same Philox stream ids, same values as sample-then-pack)
+            w = ops.bnn_sample_packed(self.mu_weight.detach(), self.rho_weight.detach(), ns, packed_mk[0], packed_mk[1], ew, ctx.seed, ctx.next_stream())
+        else:
+            w = ops.bnn_sample(self.mu_weight.detach(), self.rho_weight.detach(), ns, ew, ctx.seed, ctx.next_stream())
         b = None
         if self.bias:
             b = ops.bnn_sample(self.mu_bias.detach(), self.rho_bias.detach(), ns, eb, ctx.seed, ctx.next_stream())
@@ -242,8 +247,10 @@ class Conv2dReparameterization(_BayesBase):
 
     # pointwise interface
     def gemm_weights(self, B):
-        w, b, ns = self._sampled(B)
-        Wp = ops.pack_pw_weight(w.reshape(ns, self.out_channels, self.in_channels).contiguous())
+        if self.deterministic or not ops.USE_X6:
+            w, b, ns = self._sampled(B)
+            return ops.pack_pw_weight(w.reshape(ns, self.out_channels, self.in_channels).contiguous()), b
+        Wp, b, _ = self._sampled(B, (self.out_channels, self.in_channels))
         return Wp, b
 
     # depthwise interface
@@ -269,8 +276,11 @@ class Linear2dReparameterization(_BayesBase):
             self.rho_bias.data.fill_(self._rho_init())
 
     def gemm_weights(self, B):
-        w, b, ns = self._sampled(B)
-        return ops.pack_pw_weight(w.contiguous()), b
+        if self.deterministic or not ops.USE_X6:
+            w, b, ns = self._sampled(B)
+            return ops.pack_pw_weight(w.contiguous()), b
+        Wp, b, _ = self._sampled(B, (self.out_features, self.in_features))
+        return Wp, b
 
 
 # ------------------------------------------------------------------------------------------------

@@ -54,3 +54,26 @@ __device__ __forceinline__ float bem_erf_fast(float x) {
     return copysignf(r, x);
 }
 __device__ __forceinline__ float bem_gelu_fast(float x) { return 0.5f * x * (1.f + bem_erf_fast(x * 0.70710678118654752440f)); }
+
+// Philox4x32-10 counter-based generator + Box-Muller: one N(0,1) draw per (element index, stream id) under a 64-bit seed.
+// Shared by the Bayesian weight sampler (elementwise.hip) and the fused sample-and-pack kernel (pw_gemm_x6.hip): the same
+// (i, seed, stream) gives the same draw in both.
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+__device__ __forceinline__ float philox_normal(int64_t i, uint64_t seed, uint64_t stream_id) {
+    uint32_t c[4] = {(uint32_t)i, (uint32_t)((uint64_t)i >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float u1 = ((float)(c[0] >> 8) + 1.0f) * (1.0f / 16777216.0f);   // (0, 1]
+    const float u2 = (float)(c[1] >> 8) * (1.0f / 16777216.0f);            // [0, 1)
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);   // Box-Muller
+}
+

@@ -409,25 +409,6 @@ __global__ void resize_down_kernel(const float* __restrict__ x, float* __restric
 }
 
 // ---------------------------------------------------------------- Bayesian sampling ----------
-__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
-        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-}
-
-__device__ __forceinline__ float philox_normal(int64_t i, uint64_t seed, uint64_t stream_id) {
-    uint32_t c[4] = {(uint32_t)i, (uint32_t)((uint64_t)i >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
-    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-    const float u1 = ((float)(c[0] >> 8) + 1.0f) * (1.0f / 16777216.0f);   // (0, 1]
-    const float u2 = (float)(c[1] >> 8) * (1.0f / 16777216.0f);            // [0, 1)
-    return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);   // Box-Muller
-}
-
 __global__ void randn_kernel(float* __restrict__ out, int64_t total, uint64_t seed, uint64_t stream_id) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) out[i] = philox_normal(i, seed, stream_id);

@@ -558,7 +558,48 @@ __global__ void pack_x6_kernel(const float* __restrict__ W, u32x4* __restrict__ 
     o[0] = h; o[64] = m; o[128] = l;
 }
 
+// Bayesian weight sets straight into operand order: w[set][row][k] = mu + log1p(exp(rho)) * eps, eps injected or drawn
+// with the sampler's own Philox stream (element index i = set*M*K + row*K + k, as bem_bnn_sample_f32 numbers it), split
+// and stored like pack_x6_kernel does -- the natural-order copy (one write + one read per weight and sample) is skipped.
+__global__ void sample_pack_x6_kernel(const float* __restrict__ mu, const float* __restrict__ rho, const float* __restrict__ eps_in,
+                                      u32x4* __restrict__ Wp, int M, int K, int MT, int KB, int64_t total, uint64_t seed, uint64_t stream_id) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int lane = (int)(i & 63);
+    const int64_t blk = i >> 6;
+    const int kb = (int)(blk % KB), mt = (int)((blk / KB) % MT);
+    const int64_t set = blk / ((int64_t)KB * MT);
+    const int row = mt * 32 + (lane & 31), k0 = kb * 16 + (lane >> 5) * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        v[e] = 0.f;
+        if (row < M && k0 + e < K) {
+            const int64_t idx = (int64_t)row * K + k0 + e, gi = set * M * K + idx;
+            const float eps = eps_in ? eps_in[gi] : philox_normal(gi, seed, stream_id);
+            v[e] = mu[idx] + log1pf(expf(rho[idx])) * eps;
+        }
+    }
+    u32x4 h, m, l;
+    split8(v, h, m, l);
+    u32x4* o = Wp + ((set * MT + mt) * KB + kb) * 3 * 64 + lane;
+    o[0] = h; o[64] = m; o[128] = l;
+}
+
 }  // namespace
+
+extern "C" int bem_bnn_sample_pack_x6(const float* mu, const float* rho, const float* eps_in, float* Wp, int nsets, int M, int K,
+                                      uint64_t seed, uint64_t stream_id, void* stream) {
+    BEM_REQUIRE(mu && rho && Wp, "bnn_sample_pack_x6: null tensor");
+    BEM_REQUIRE(nsets >= 0 && M > 0 && K > 0, "bnn_sample_pack_x6: bad shape");
+    BEM_REQUIRE(((uintptr_t)Wp & 15) == 0, "bnn_sample_pack_x6: output must be 16-byte aligned");
+    if (nsets == 0) return BEM_OK;
+    const int MT = cdiv(M, 32), KB = cdiv(K, 16);
+    const int64_t total = (int64_t)nsets * MT * KB * 64;
+    sample_pack_x6_kernel<<<(unsigned)cdiv64(total, 256), 256, 0, (hipStream_t)stream>>>(mu, rho, eps_in, reinterpret_cast<u32x4*>(Wp), M, K, MT, KB,
+                                                                                       total, seed, stream_id);
+    return bem_check_launch("bnn_sample_pack_x6");
+}
 
 extern "C" int64_t bem_pw_x6_packed_elems(int M, int K) {       // in floats (4 per 16-byte vector)
     return (int64_t)cdiv(M, 32) * cdiv(K, 16) * 3 * 64 * 4;

@@ -120,6 +120,11 @@ int64_t bem_pw_packed_elems(int M, int K);
 int bem_pw_gemm_x6_f32(const bem_pw_args* a, void* stream);
 int bem_pack_pw_weight_x6(const float* W, float* Wp, int nsets, int M, int K, void* stream);
 int64_t bem_pw_x6_packed_elems(int M, int K);
+/* bem_bnn_sample_f32 (below) and bem_pack_pw_weight_x6 in one pass for the weights of a Bayesian 1x1 layer: nsets weight
+ * sets w = mu + log1p(exp(rho)) * eps written straight in x6 operand order; eps (nsets, M, K) injected or NULL = the
+ * sampler's Philox draws for (seed, stream_id) -- identical values to sampling first and packing afterwards. */
+int bem_bnn_sample_pack_x6(const float* mu, const float* rho, const float* eps, float* Wp, int nsets, int M, int K,
+                           uint64_t seed, uint64_t stream_id, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused gdMlp block (vmamba.py:116-133 + the norm2 / residual around it, vmamba.py:1330-1333):

@@ -524,3 +524,15 @@ def test_transpose_plane_slice_and_strided_scan_inputs(ops):
     a = ops.ss2d_scan(dev(x0), dev(x1), wd[:, :2], wd[:, 2:], dev(dtw), dev(dtb), dev(A), dev(Ds))
     b = ops.ss2d_scan(dev(x0), dev(x1), wd[:, :2].contiguous(), wd[:, 2:].contiguous(), dev(dtw), dev(dtb), dev(A), dev(Ds))
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_bnn_sample_packed_equals_sample_then_pack(ops):
+    """bem_bnn_sample_pack_x6 = bem_bnn_sample_f32 followed by bem_pack_pw_weight_x6, bit for bit (Philox and injected eps)."""
+    g = torch.Generator().manual_seed(3)
+    M, K, ns = 40, 23, 3
+    mu, rho = torch.randn(M, K, generator=g), torch.randn(M, K, generator=g) - 3
+    eps = torch.randn(ns, M, K, generator=g)
+    for e in (None, dev(eps)):
+        a = ops.bnn_sample_packed(dev(mu), dev(rho), ns, M, K, e, seed=11, stream_id=5)
+        b = ops.pack_pw_weight(ops.bnn_sample(dev(mu), dev(rho), ns, e, seed=11, stream_id=5), x6=True)
+        assert a.shape == b.shape and torch.equal(a.view(torch.int32), b.view(torch.int32))
