@@ -426,12 +426,11 @@ __global__ __launch_bounds__(256, 2) void pw_x6_res_kernel(PwX k) {
 // stream: any K, no LayerNorm.  grid (ceil(L / 256), ceil(MT / MTW), B); x one k-block ahead of the MFMAs.
 // ------------------------------------------------------------------------------------------------
 constexpr int BEM_X6_MAXK_LN = 1024;      // LayerNorm parameters of the streaming form live in LDS
-template <int MTW, bool SUM, bool VEC, bool LN>
+template <int MTW, int NSUB, bool SUM, bool VEC, bool LN>
 __global__ __launch_bounds__(256, 2) void pw_x6_stream_kernel(PwX k) {
-    constexpr int NSUB = 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kh = lane >> 5, n = lane & 31;
     const int b = blockIdx.z, mt0 = blockIdx.y * MTW;
-    const int p0 = (xcd_tile(blockIdx.x, gridDim.x) * 4 + wave) * 64;
+    const int p0 = (xcd_tile(blockIdx.x, gridDim.x) * 4 + wave) * (32 * NSUB);
     __shared__ __attribute__((aligned(16))) float s_bias[BEM_X6_MAXM];
     __shared__ float s_ln[LN ? 2 * BEM_X6_MAXK_LN : 2];
     stage_bias(k, b, s_bias);
@@ -443,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void pw_x6_stream_kernel(PwX k) {
     }
     __syncthreads();                    // the only barrier, before any early exit
     if (p0 >= k.L) return;
-    const int p = p0 + 2 * n;
+    const int p = p0 + NSUB * n;
     bool keep[NSUB];
 #pragma unroll
     for (int t = 0; t < NSUB; ++t) keep[t] = p + t < k.L;
@@ -457,7 +456,9 @@ __global__ __launch_bounds__(256, 2) void pw_x6_stream_kernel(PwX k) {
     float mean[NSUB], rstd[NSUB];
     if (LN) {
         const float inv = 1.f / (float)k.K;
-        float s[NSUB] = {0.f, 0.f};
+        float s[NSUB];
+#pragma unroll
+        for (int t = 0; t < NSUB; ++t) s[t] = 0.f;
         for (int kb = 0; kb < k.KB; ++kb) {
             float v[8][NSUB];
             load_x(kb, v);
@@ -468,7 +469,9 @@ __global__ __launch_bounds__(256, 2) void pw_x6_stream_kernel(PwX k) {
         }
 #pragma unroll
         for (int t = 0; t < NSUB; ++t) { s[t] += __shfl_xor(s[t], 32, 64); mean[t] = s[t] * inv; }
-        float q[NSUB] = {0.f, 0.f};
+        float q[NSUB];
+#pragma unroll
+        for (int t = 0; t < NSUB; ++t) q[t] = 0.f;
         for (int kb = 0; kb < k.KB; ++kb) {
             float v[8][NSUB];
             load_x(kb, v);
@@ -665,16 +668,25 @@ extern "C" int bem_pw_gemm_x6_f32(const bem_pw_args* a, void* stream) {
     if (ln && k.KB <= 10) { if (k.MT == 1) BEM_X6_RES(10, 1, 1); else BEM_X6_RES(10, 1, 2); }
 #undef BEM_X6_RES
     {
-        const int mtw = k.MT == 1 ? 1 : 2;         // two M-tiles per pass over x: every extra grid.y slice re-reads the input
-        dim3 grid(cdiv(a->L, 256), cdiv(k.MT, mtw), a->B);
+        // M-tiles per pass over x: every extra grid.y slice re-reads the input.  Two with 64-pixel waves; for exactly three
+        // M-tiles (level-1 project_out, M = 80) three with 32-pixel waves -- half the bytes per load / store instruction,
+        // but x is read once instead of twice
+        // (measured: 227 us vs 219 us for the two-slice form at K = 320, M = 80, 64x64 -- the re-read is served by L2; kept off)
+        const bool three = false && k.MT == 3 && !ln;
+        const int mtw = three ? 3 : (k.MT == 1 ? 1 : 2);
+        dim3 grid(cdiv(a->L, three ? 128 : 256), cdiv(k.MT, mtw), a->B);
 #define BEM_X6_STREAM(MTW, LN)                                                                \
     do {                                                                                      \
-        if (vec && !sum) pw_x6_stream_kernel<MTW, false, true, LN><<<grid, 256, 0, s>>>(k);   \
-        else if (vec) pw_x6_stream_kernel<MTW, true, true, LN><<<grid, 256, 0, s>>>(k);       \
-        else if (!sum) pw_x6_stream_kernel<MTW, false, false, LN><<<grid, 256, 0, s>>>(k);    \
-        else pw_x6_stream_kernel<MTW, true, false, LN><<<grid, 256, 0, s>>>(k);               \
+        if (vec && !sum) pw_x6_stream_kernel<MTW, 2, false, true, LN><<<grid, 256, 0, s>>>(k);   \
+        else if (vec) pw_x6_stream_kernel<MTW, 2, true, true, LN><<<grid, 256, 0, s>>>(k);       \
+        else if (!sum) pw_x6_stream_kernel<MTW, 2, false, false, LN><<<grid, 256, 0, s>>>(k);    \
+        else pw_x6_stream_kernel<MTW, 2, true, false, LN><<<grid, 256, 0, s>>>(k);               \
     } while (0)
-        if (ln) { if (mtw == 1) BEM_X6_STREAM(1, true); else BEM_X6_STREAM(2, true); }
+        if (three) {
+            if (!sum) pw_x6_stream_kernel<3, 1, false, false, false><<<grid, 256, 0, s>>>(k);
+            else pw_x6_stream_kernel<3, 1, true, false, false><<<grid, 256, 0, s>>>(k);
+        }
+        else if (ln) { if (mtw == 1) BEM_X6_STREAM(1, true); else BEM_X6_STREAM(2, true); }
         else { if (mtw == 1) BEM_X6_STREAM(1, false); else BEM_X6_STREAM(2, false); }
 #undef BEM_X6_STREAM
     }
