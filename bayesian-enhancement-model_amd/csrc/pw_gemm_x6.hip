@@ -507,9 +507,12 @@ __global__ __launch_bounds__(256, 2) void pw_x6_stream_kernel(PwX k) {
             }
         }
     };
-    float xn[8][NSUB];
+    // x two k-blocks ahead (the HBM stream: with 2 waves per SIMD one block in flight per wave covers ~4 TB/s at 2 us of
+    // latency), weights one ahead (L1 / L2)
+    float xn[8][NSUB], xn2[8][NSUB];
     u32x4 wn[MTW][3];
     load_x(0, xn);
+    load_x(1, xn2);
     load_w(0, wn);
     for (int kb = 0; kb < k.KB; ++kb) {
         u32x4 xl[NSUB][3], wc[MTW][3];
@@ -527,7 +530,11 @@ __global__ __launch_bounds__(256, 2) void pw_x6_stream_kernel(PwX k) {
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
             for (int li = 0; li < 3; ++li) wc[m][li] = wn[m][li];
-        load_x(kb + 1, xn);          // past the end: clamped channel, masked to zero, never used
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int t = 0; t < NSUB; ++t) xn[e][t] = xn2[e][t];
+        load_x(kb + 2, xn2);         // past the end: clamped channel, masked to zero, never used
         load_w(kb + 1, wn);
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
