@@ -640,7 +640,7 @@ _KEYS = {
                          lambda K, M, ln, L, mode: USE_X6 and K <= 48 and L % 2 == 0 and mode != 1),
     # the streaming x6 GEMM with two M-tiles per pass (project_out / out_proj / fuse 1x1 at K > 48 without LayerNorm):
     # the kernel with the largest share of the step in profiles/r01_bench_kernel_stats.csv
-    "pw_x6_stream<2>": ("pw_gemm", "hbm", "pw_x6_stream_kernel<2, false, true, false>",
+    "pw_x6_stream<2>": ("pw_gemm", "hbm", "pw_x6_stream_kernel<2, 2, false, true, false>",
                         lambda K, M, ln, L, mode: USE_X6 and K > 48 and not ln and M > 32 and L % 2 == 0 and mode != 1),
     # the same role in the f32-MFMA build (BEM_PW_X6=0)
     "pw_gemm3_reg<20,2>": ("pw_gemm", "hbm", "pw_gemm3_reg_kernel<20, 2, true, false>", lambda K, M, ln, L, mode: K <= 40 and M > 32 and L % 4 == 0 and mode != 1),
