@@ -69,11 +69,24 @@ __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uin
     }
 }
 
-__device__ __forceinline__ float philox_normal(int64_t i, uint64_t seed, uint64_t stream_id) {
-    uint32_t c[4] = {(uint32_t)i, (uint32_t)((uint64_t)i >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
+// Four N(0,1) draws of counter block j (elements 4j .. 4j+3): both Box-Muller outputs of the two uniform pairs.
+__device__ __forceinline__ void philox_normal4(int64_t j, uint64_t seed, uint64_t stream_id, float (&z)[4]) {
+    uint32_t c[4] = {(uint32_t)j, (uint32_t)((uint64_t)j >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
     philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-    const float u1 = ((float)(c[0] >> 8) + 1.0f) * (1.0f / 16777216.0f);   // (0, 1]
-    const float u2 = (float)(c[1] >> 8) * (1.0f / 16777216.0f);            // [0, 1)
-    return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);   // Box-Muller
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float u1 = ((float)(c[2 * h] >> 8) + 1.0f) * (1.0f / 16777216.0f);   // (0, 1]
+        const float u2 = (float)(c[2 * h + 1] >> 8) * (1.0f / 16777216.0f);        // [0, 1)
+        const float r = sqrtf(-2.0f * logf(u1));
+        float sn, cs;
+        sincosf(6.28318530717958647692f * u2, &sn, &cs);
+        z[2 * h] = r * cs;
+        z[2 * h + 1] = r * sn;
+    }
 }
-
+// draw of element i = component i & 3 of block i >> 2 (one Philox call serves four consecutive elements)
+__device__ __forceinline__ float philox_normal(int64_t i, uint64_t seed, uint64_t stream_id) {
+    float z[4];
+    philox_normal4(i >> 2, seed, stream_id, z);
+    return z[i & 3];
+}

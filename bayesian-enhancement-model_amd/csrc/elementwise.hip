@@ -414,19 +414,24 @@ __global__ void randn_kernel(float* __restrict__ out, int64_t total, uint64_t se
     if (i < total) out[i] = philox_normal(i, seed, stream_id);
 }
 
+// one thread = four consecutive elements = one Philox counter block
 __global__ void bnn_sample_kernel(const float* __restrict__ mu, const float* __restrict__ rho,
                                   const float* __restrict__ eps_in, float* __restrict__ out, int64_t n, int64_t total,
                                   uint64_t seed, uint64_t stream_id) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int64_t e = i % n;
-    float eps;
-    if (eps_in) {
-        eps = eps_in[i];
-    } else {
-        eps = philox_normal(i, seed, stream_id);
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i0 = 4 * j;
+    if (i0 >= total) return;
+    float z[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!eps_in) philox_normal4(j, seed, stream_id, z);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t i = i0 + q;
+        if (i < total) {
+            const int64_t e = i % n;
+            const float eps = eps_in ? eps_in[i] : z[q];
+            out[i] = mu[e] + log1pf(expf(rho[e])) * eps;
+        }
     }
-    out[i] = mu[e] + log1pf(expf(rho[e])) * eps;
 }
 
 // ---------------------------------------------------------------- Monte-Carlo loop pieces ----
@@ -703,7 +708,7 @@ extern "C" int bem_bnn_sample_f32(const float* mu, const float* rho, const float
     BEM_REQUIRE(nsets >= 0 && n >= 0, "bnn_sample: bad shape");
     const int64_t total = (int64_t)nsets * n;
     if (total == 0) return BEM_OK;
-    bnn_sample_kernel<<<GRID1D(total), 256, 0, (hipStream_t)stream>>>(mu, rho, eps_in, out, n, total, seed, stream_id);
+    bnn_sample_kernel<<<GRID1D(cdiv64(total, 4)), 256, 0, (hipStream_t)stream>>>(mu, rho, eps_in, out, n, total, seed, stream_id);
     return bem_check_launch("bnn_sample");
 }
 

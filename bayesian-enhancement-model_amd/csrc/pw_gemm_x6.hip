@@ -581,12 +581,23 @@ __global__ void sample_pack_x6_kernel(const float* __restrict__ mu, const float*
     const int64_t set = blk / ((int64_t)KB * MT);
     const int row = mt * 32 + (lane & 31), k0 = kb * 16 + (lane >> 5) * 8;
     float v[8];
+    // the lane's 8 consecutive k of one row are 8 consecutive element indices: at most 3 Philox counter blocks
+    const int64_t g0 = set * M * K + (int64_t)row * K + k0;
+    float z[3][4];
+    if (!eps_in && row < M) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) philox_normal4((g0 >> 2) + q, seed, stream_id, z[q]);
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         v[e] = 0.f;
         if (row < M && k0 + e < K) {
-            const int64_t idx = (int64_t)row * K + k0 + e, gi = set * M * K + idx;
-            const float eps = eps_in ? eps_in[gi] : philox_normal(gi, seed, stream_id);
+            const int64_t idx = (int64_t)row * K + k0 + e, gi = g0 + e;
+            const int off = (int)(g0 & 3);                                // position of the first element in its block
+            // z[(off + e) >> 2][(off + e) & 3] with compile-time indices (a runtime index would put z into scratch)
+            const float zsel = off == 0 ? z[e >> 2][e & 3] : off == 1 ? z[(e + 1) >> 2][(e + 1) & 3]
+                             : off == 2 ? z[(e + 2) >> 2][(e + 2) & 3] : z[(e + 3) >> 2][(e + 3) & 3];
+            const float eps = eps_in ? eps_in[gi] : zsel;
             v[e] = mu[idx] + log1pf(expf(rho[idx])) * eps;
         }
     }
