@@ -39,6 +39,9 @@ class _Cache:
         return val
 
 
+# dw3x3 + gate fused into the project_out loader (bem_gate_proj_x6_f32): correct (tests/test_ops_gpu.py) but VALU-bound at one
+# pixel per lane -- 189 vs 232 img/s end to end -- so off by default
+GATE_PROJ = __import__("os").environ.get("BEM_GATE_PROJ", "0") != "0"
 FUSE_GDMLP = os.environ.get("BEM_FUSE_GDMLP", "0") != "0"    # 0: unfused three-kernel gdMlp (kept for A/B checks)
 
 
@@ -332,6 +335,13 @@ class gdMlp(nn.Module):
             Wpi, bpi, dww, dwb, Wpo, bpo = self._fused_params(B)
             return ops.gdmlp_fused(x, norm.weight.detach(), norm.bias.detach(), norm.eps, Wpi, bpi, dww, dwb, Wpo, bpo, Hd)
         Wp, b = self.project_in.gemm_weights(B)
+        if GATE_PROJ and ops.USE_X6:
+            # depthwise 3x3 + gate inside the loader of project_out: the gated Hd-channel tensor never exists in HBM
+            t = ops.empty_padded((B, 2 * Hd) + tuple(x.shape[2:]), x.device)
+            ops.pw_gemm(x, Wp, _out_features(self.project_in), ln=(norm.weight.detach(), norm.bias.detach()), ln_eps=norm.eps, bias=b, out=t)
+            w, bw = self.dwconv.dw_weights(B)
+            Wp, b = self.project_out.gemm_weights(B)
+            return ops.gate_proj(t, w, bw, Wp, _out_features(self.project_out), bias=b, res=x)
         t = ops.pw_gemm(x, Wp, _out_features(self.project_in), ln=(norm.weight.detach(), norm.bias.detach()),
                         ln_eps=norm.eps, bias=b)
         w, b = self.dwconv.dw_weights(B)

@@ -225,6 +225,48 @@ def pw_gemm(x1, Wp, M, *, x2=None, in_mode=0, ln=None, ln_eps=1e-5, bias=None, r
     return out
 
 
+def empty_padded(shape, device, pad=4):
+    """Contiguous float32 tensor of ``shape`` that may be read ``pad`` elements before its first and after its last element
+    (it is a view into a larger allocation; the 16-byte alignment of a fresh allocation is kept for pad % 4 == 0)."""
+    n = 1
+    for s_ in shape:
+        n *= s_
+    buf = torch.empty(n + 2 * pad, device=device, dtype=torch.float32)
+    return buf[pad:pad + n].view(shape)
+
+
+def gate_proj(h, dww, dwb, Wp, M, bias=None, res=None):
+    """res + W_o * (GELU(dw3x3(h)[:Hd]) * dw3x3(h)[Hd:]) + bias in one kernel (bem_gate_proj_x6_f32).
+    h (B,2Hd,H,W) from ``empty_padded``; dww (2Hd,1,3,3) or (B,2Hd,1,3,3); dwb (2Hd) | (B,2Hd) | None; Wp x6-packed (1|B, ...)."""
+    _chk(h, "h"); _chk(dww, "dww"); _chk(dwb, "dwb", optional=True); _chk(Wp, "Wp"); _chk(bias, "bias", optional=True); _chk(res, "res", optional=True)
+    B, C2, H, W = h.shape
+    Hd = C2 // 2
+    st = h.untyped_storage()
+    if C2 % 2 or h.storage_offset() < 1 or st.nbytes() < 4 * (h.storage_offset() + h.numel() + 1):
+        raise ValueError("gate_proj: h must have an even channel count and one readable element before / after it (ops.empty_padded)")
+    per_b = dww.dim() == 5
+    if tuple(dww.shape[-4:]) != (C2, 1, 3, 3) or (per_b and dww.shape[0] != B):
+        raise ValueError(f"gate_proj: depthwise weight {tuple(dww.shape)} vs {C2} channels")
+    bb = 0
+    if dwb is not None:
+        if dwb.shape[-1] != C2 or (dwb.dim() == 2 and dwb.shape[0] not in (1, B)):
+            raise ValueError("gate_proj: depthwise bias shape")
+        bb = C2 if (dwb.dim() == 2 and dwb.shape[0] == B and B > 1) else 0
+    if Wp.dim() != 2 or Wp.shape[1] != packed_elems(M, Hd, True) or Wp.shape[0] not in (1, B) or getattr(Wp, "_bem_mk", (M, Hd)) != (M, Hd):
+        raise ValueError(f"gate_proj: packed weight {tuple(Wp.shape)} does not match M={M} K={Hd} (x6 format)")
+    ob = 0
+    if bias is not None:
+        if bias.shape[-1] != M or (bias.dim() == 2 and bias.shape[0] not in (1, B)):
+            raise ValueError("gate_proj: bias shape")
+        ob = M if (bias.dim() == 2 and bias.shape[0] > 1) else 0
+    if res is not None and tuple(res.shape) != (B, M, H, W):
+        raise ValueError("gate_proj: residual shape")
+    out = torch.empty(B, M, H, W, device=h.device, dtype=h.dtype)
+    check(lib().bem_gate_proj_x6_f32(_p(h), _p(dww), (C2 * 9 if per_b else 0), _p(dwb), bb, _p(Wp), (Wp.shape[1] if Wp.shape[0] > 1 else 0),
+                                     _p(bias), ob, _p(res), _p(out), B, Hd, M, H, W, _stream()), "gate_proj")
+    return out
+
+
 def pack_pw_weight_gate(W, Hd):
     """project_in weight (2Hd,K) or (nsets,2Hd,K) -> packed with gate rows regrouped per 16 channels."""
     _chk(W, "W")

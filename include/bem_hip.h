@@ -256,6 +256,16 @@ int bem_candidate_finalize_f32(const float* pred, const float* target, float* fi
 int bem_select_best_f32(const float* cand, const float* psnr, int* best, float* best_psnr, float* best_img, int B, int N,
                         int64_t chw, void* stream);
 
+/* gdMlp tail (vmamba.py:124-133) in one kernel: out = res + W_o * ( GELU(dw3x3(h)[0:Hd]) * dw3x3(h)[Hd:2Hd] ) + bias.
+ * h (B,2Hd,H,W) = project_in output; it must be readable ONE ELEMENT BEFORE ITS FIRST AND AFTER ITS LAST element (the 3x3
+ * window of a plane's first / last pixel is fetched unclamped and masked) -- allocate it inside a larger buffer.
+ * dww (2Hd,9) / dwb (2Hd)|NULL depthwise parameters, *_bstride elements between per-batch-row sets (0 = shared);
+ * Wp = bem_pack_pw_weight_x6 of W_o (M,Hd), w_bstride / bias_bstride as in bem_pw_args; res (B,M,H,W) or NULL.
+ * The gated tensor is never written: the depthwise conv + gate run in the loader of the x6 GEMM. */
+int bem_gate_proj_x6_f32(const float* h, const float* dww, int64_t dww_bstride, const float* dwb, int64_t dwb_bstride,
+                         const float* Wp, int64_t w_bstride, const float* bias, int64_t bias_bstride, const float* res,
+                         float* out, int B, int Hd, int M, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
