@@ -108,13 +108,20 @@ __device__ __forceinline__ float dpp_from_next_lane(float v) {   // lane l <- la
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
 }
 
+template <bool DPPHALO>
 __device__ __forceinline__ void dw_block_fast(const float* __restrict__ plane, int H, int W, int y0, int x0,
                                               const float* __restrict__ w9, float (&acc)[RB][4]) {
     float4 c[RB + 2];
+    float hl[RB + 2], hr[RB + 2];       // halo columns x0 - 1, x0 + 4 when they cannot come from the neighbouring lanes
 #pragma unroll
     for (int ry = -1; ry <= RB; ++ry) {
         const int yy = min(max(y0 + ry, 0), H - 1);
-        c[ry + 1] = *reinterpret_cast<const float4*>(plane + (int64_t)yy * W + x0);
+        const float* r = plane + (int64_t)yy * W;
+        c[ry + 1] = *reinterpret_cast<const float4*>(r + x0);
+        if (!DPPHALO) {                 // clamped addresses; masked by ml / mr below
+            hl[ry + 1] = r[max(x0 - 1, 0)];
+            hr[ry + 1] = r[min(x0 + 4, W - 1)];
+        }
     }
     float wk[9];
 #pragma unroll
@@ -126,7 +133,8 @@ __device__ __forceinline__ void dw_block_fast(const float* __restrict__ plane, i
         float4 q = c[ry + 1];
         if (ry == -1) { q.x *= mt; q.y *= mt; q.z *= mt; q.w *= mt; }
         if (ry == RB) { q.x *= mb; q.y *= mb; q.z *= mb; q.w *= mb; }
-        const float v[6] = {dpp_from_prev_lane(q.w) * ml, q.x, q.y, q.z, q.w, dpp_from_next_lane(q.x) * mr};
+        const float v[6] = {(DPPHALO ? dpp_from_prev_lane(q.w) : hl[ry + 1] * ((ry == -1) ? mt : (ry == RB) ? mb : 1.f)) * ml, q.x, q.y, q.z, q.w,
+                            (DPPHALO ? dpp_from_next_lane(q.x) : hr[ry + 1] * ((ry == -1) ? mt : (ry == RB) ? mb : 1.f)) * mr};
 #pragma unroll
         for (int oy = 0; oy < RB; ++oy) {
             const int dy = ry - oy;
@@ -138,7 +146,7 @@ __device__ __forceinline__ void dw_block_fast(const float* __restrict__ plane, i
     }
 }
 
-template <int MODE>
+template <int MODE, bool DPPHALO>
 __global__ __launch_bounds__(256) void dwconv3x3_fast_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              int64_t w_bs, const float* __restrict__ bias, int64_t b_bs,
                                                              float* __restrict__ out, int Cout, int H, int W) {
@@ -161,8 +169,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_fast_kernel(const float* __rest
     for (int r = 0; r < RB; ++r)
 #pragma unroll
         for (int j = 0; j < 4; ++j) a0[r][j] = a1[r][j] = 0.f;
-    dw_block_fast(pl, H, W, y0, x0, wb + (int64_t)c * 9, a0);
-    if (MODE == 2) dw_block_fast(x + ((int64_t)b * Cin + c + Cout) * HW, H, W, y0, x0, wb + (int64_t)(c + Cout) * 9, a1);
+    dw_block_fast<DPPHALO>(pl, H, W, y0, x0, wb + (int64_t)c * 9, a0);
+    if (MODE == 2) dw_block_fast<DPPHALO>(x + ((int64_t)b * Cin + c + Cout) * HW, H, W, y0, x0, wb + (int64_t)(c + Cout) * 9, a1);
     float4 self[RB];
     if (MODE == 3) {
 #pragma unroll
@@ -551,12 +559,18 @@ extern "C" int bem_dwconv3x3_f32(const float* x, const float* w, int64_t w_bstri
     if (B == 0) return BEM_OK;
     dim3 grid(cdiv(cdiv(H, RB) * ((W + 3) / 4), 256), Cout, B);
     hipStream_t s = (hipStream_t)stream;
-    const bool fast = W % 4 == 0 && 64 % (W / 4) == 0 && H % RB == 0 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0;
+    // branch-free forms: W % 4 == 0 and H % RB == 0; the halo columns come from the neighbouring lanes (DPP) when a wavefront
+    // covers whole image rows (64 % (W / 4) == 0: every plane of a 256x256 image), else from two more clamped loads per row
+    const bool fast = W % 4 == 0 && H % RB == 0 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0;
+    const bool dpp = fast && 64 % (W / 4) == 0;
+#define BEM_DW(MODE) do { if (dpp) dwconv3x3_fast_kernel<MODE, true><<<grid, 256, 0, s>>>(x, w, w_bstride, bias, bias_bstride, out, Cout, H, W); \
+                          else dwconv3x3_fast_kernel<MODE, false><<<grid, 256, 0, s>>>(x, w, w_bstride, bias, bias_bstride, out, Cout, H, W); } while (0)
     if (!fast) dwconv3x3_kernel<<<grid, 256, 0, s>>>(x, w, w_bstride, bias, bias_bstride, out, Cout, H, W, mode);
-    else if (mode == 0) dwconv3x3_fast_kernel<0><<<grid, 256, 0, s>>>(x, w, w_bstride, bias, bias_bstride, out, Cout, H, W);
-    else if (mode == 1) dwconv3x3_fast_kernel<1><<<grid, 256, 0, s>>>(x, w, w_bstride, bias, bias_bstride, out, Cout, H, W);
-    else if (mode == 2) dwconv3x3_fast_kernel<2><<<grid, 256, 0, s>>>(x, w, w_bstride, bias, bias_bstride, out, Cout, H, W);
-    else dwconv3x3_fast_kernel<3><<<grid, 256, 0, s>>>(x, w, w_bstride, bias, bias_bstride, out, Cout, H, W);
+    else if (mode == 0) BEM_DW(0);
+    else if (mode == 1) BEM_DW(1);
+    else if (mode == 2) BEM_DW(2);
+    else BEM_DW(3);
+#undef BEM_DW
     return bem_check_launch("dwconv3x3");
 }
 

@@ -203,7 +203,8 @@ def test_conv_transpose_2x2(ops, cfg):
 
 # ----------------------------------------------------------------------------- convolutions -----
 @pytest.mark.parametrize("cfg", [(2, 8, 9, 13), (1, 40, 16, 12), (1, 3, 1, 1), (2, 4, 33, 64),
-                                 (2, 8, 16, 64), (1, 6, 8, 8), (2, 4, 32, 128), (1, 4, 4, 4), (1, 2, 8, 256)])   # second row: whole-rows-per-wavefront fast form
+                                 (2, 8, 16, 64), (1, 6, 8, 8), (2, 4, 32, 128), (1, 4, 4, 4), (1, 2, 8, 256),   # whole-rows-per-wavefront fast form (DPP halo)
+                                 (1, 4, 8, 80), (2, 6, 12, 320), (1, 3, 4, 12), (1, 2, 56, 80)])                 # W % 4 == 0, halo columns by clamped loads
 def test_dwconv_modes(ops, cfg):
     B, C, H, W = cfg
     g = torch.Generator().manual_seed(C * H)
