@@ -42,6 +42,7 @@ class _Cache:
 # dw3x3 + gate fused into the project_out loader (bem_gate_proj_x6_f32): correct (tests/test_ops_gpu.py) but VALU-bound at one
 # pixel per lane -- 189 vs 232 img/s end to end -- so off by default
 GATE_PROJ = __import__("os").environ.get("BEM_GATE_PROJ", "0") != "0"
+SCAN_RM = os.environ.get("BEM_SCAN_RM", "1") != "0"          # row-major SS2D scan (no transposes of xc / y1) where the plane size allows
 FUSE_GDMLP = os.environ.get("BEM_FUSE_GDMLP", "0") != "0"    # 0: unfused three-kernel gdMlp (kept for A/B checks)
 
 
@@ -406,6 +407,15 @@ class SS2D(nn.Module):
         w, b = self.conv2d.dw_weights(B)
         xc = ops.dwconv3x3(t, w, b, mode=1)
         wall, dtw, dtb, A, Ds = self._scan_params()
+        Wp, b = self.out_proj.gemm_weights(B)
+        on = self.out_norm
+        if SCAN_RM and ops.ss2d_scan_rm_supported(H, W, R):
+            # row-major scan: no transposed copy of xc, y1 comes back row-major (the column orientation goes through LDS)
+            xd = ops.pw_gemm(xc, wall, 4 * (R + 2))
+            xd1 = ops.transpose_plane_slice(xd, 2 * (R + 2), 2 * (R + 2))
+            y0, y1 = ops.ss2d_scan_rm(xc, xd.view(B, 4, R + 2, L)[:, :2], xd1.view(B, 2, R + 2, L), dtw, dtb, A, Ds)
+            return ops.pw_gemm(y0, Wp, _out_features(self.out_proj), x2=y1, in_mode=1,
+                               ln=(on.weight.detach(), on.bias.detach()), ln_eps=on.eps, bias=b, res=x)
         xcT = ops.transpose_planes(xc)
         # x_dbl of the column-major directions = the row-major GEMM's rows in transposed pixel order: 2 (R+2) planes to
         # transpose instead of a second GEMM pass over the C planes of xcT
@@ -414,8 +424,6 @@ class SS2D(nn.Module):
         y0, y1 = ops.ss2d_scan(xc.view(B, Ci, L), xcT.view(B, Ci, L), xd.view(B, 4, R + 2, L)[:, :2], xd1.view(B, 2, R + 2, L),
                                dtw, dtb, A, Ds)
         y1r = ops.transpose_planes(y1.view(B, Ci, W, H))
-        Wp, b = self.out_proj.gemm_weights(B)
-        on = self.out_norm
         return ops.pw_gemm(y0.view(B, Ci, H, W), Wp, _out_features(self.out_proj), x2=y1r, in_mode=1,
                            ln=(on.weight.detach(), on.bias.detach()), ln_eps=on.eps, bias=b, res=x)
 

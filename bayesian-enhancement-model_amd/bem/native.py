@@ -54,6 +54,8 @@ SIGNATURES = {
     "bem_cross_merge_f32": [P, P, I, I, I, I, P],
     "bem_ss2d_scan_f32": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
     "bem_ss2d_scan_strided_f32": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I64, I64, P],
+    "bem_ss2d_scan_rm_supported": [I, I, I],
+    "bem_ss2d_scan_rm_f32": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I64, I64, P],
     "bem_pw_gemm_f32": [ctypes.POINTER(PwArgs), P],
     "bem_pack_pw_weight_f32": [P, P, I, I, I, P],
     "bem_pw_packed_elems": [I, I],

@@ -124,6 +124,34 @@ def ss2d_scan(x0, x1, xd0, xd1, dtw, dtb, A, Ds):
     return y0, y1
 
 
+def ss2d_scan_rm_supported(H, W, R):
+    return bool(lib().bem_ss2d_scan_rm_supported(H, W, R))
+
+
+def ss2d_scan_rm(x, xd0, xd1, dtw, dtb, A, Ds):
+    """Row-major form: x (B,C,H,W); xd0 (B,2,R+2,L) row-major order, xd1 (B,2,R+2,L) transposed pixel order (either may be
+    a batch-strided channel slice); returns y0, y1 both (B,C,H,W) row-major."""
+    for n, t in (("x", x), ("dtw", dtw), ("dtb", dtb), ("A", A), ("Ds", Ds)):
+        _chk(t, n)
+    B, C, H, W = x.shape
+    L, R = H * W, dtw.shape[2]
+    if not ss2d_scan_rm_supported(H, W, R):
+        raise ValueError(f"ss2d_scan_rm: plane {H}x{W} / dt_rank {R} not supported")
+    if xd0.shape != (B, 2, R + 2, L) or xd1.shape != xd0.shape or dtw.shape != (4, C, R) or dtb.shape != (4, C) or A.numel() != 4 * C or Ds.numel() != 4 * C:
+        raise ValueError("ss2d_scan_rm: shapes")
+    bs = []
+    for n, t in (("xd0", xd0), ("xd1", xd1)):
+        if not t.is_cuda or t.dtype != torch.float32:
+            raise native.BemNativeError(f"{n} must be a float32 CUDA/HIP tensor")
+        if t.stride()[1:] != ((R + 2) * L, L, 1) or (B > 1 and (t.stride(0) < 2 * (R + 2) * L or t.stride(0) % 4)):
+            raise ValueError(f"{n}: only the batch stride may differ from a contiguous (B,2,R+2,L) tensor")
+        bs.append(t.stride(0) if B > 1 else 0)
+    y0, y1 = torch.empty_like(x), torch.empty_like(x)
+    check(lib().bem_ss2d_scan_rm_f32(_p(x), _p(xd0), _p(xd1), _p(dtw), _p(dtb), _p(A), _p(Ds), _p(y0), _p(y1), B, C, H, W, R, bs[0], bs[1], _stream()),
+          "ss2d_scan_rm")
+    return y0, y1
+
+
 def transpose_plane_slice(x, c0, C):
     """x (B,Ct,H,W) contiguous -> transposed planes of channels [c0, c0+C): (B,C,W,H) contiguous."""
     _chk(x, "x")

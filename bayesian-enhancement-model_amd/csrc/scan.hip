@@ -567,16 +567,20 @@ __device__ __forceinline__ void wave_scan_affine(float& P, float& S, float& Pe, 
 }
 #undef BEM_SCAN_STEP
 
-template <int NT, int T, int CB, int R, int MINW>
+// TR: orientation 1 works on the ROW-MAJOR planes too (x1 = x0's tensor, y1 written row-major): a workgroup of that
+// orientation stages its CB planes in LDS (row pitch W + 1), reads its column-major scan positions from there and sends
+// its result back through the same buffer, so neither the transposed copy of x nor the transposed y exist in HBM.
+template <int NT, int T, int CB, int R, int MINW, bool TR>
 __global__ __launch_bounds__(NT, MINW) void ss2d_scan_rows_kernel(
     // x / x_dbl deliberately not __restrict__: their loads must stay behind the barrier of the channel step they belong
     // to (as invariant loads the compiler hoists all CB * T * 2 steps' loads to the top and runs out of registers)
     const float* x0, const float* x1, const float* xd0, const float* xd1, const float* __restrict__ dtw,
     const float* __restrict__ dtb, const float* __restrict__ A, const float* __restrict__ Ds, float* y0, float* y1,
-    int Bn, int C, int64_t xbs0, int64_t xbs1) {
+    int Bn, int C, int64_t xbs0, int64_t xbs1, int Himg) {
     constexpr int NW = NT / BEM_WAVE, L = NT * 4 * T;
     constexpr int NSLOT = CB > 1 ? CB : 2;
     __shared__ float agg[NSLOT][2 * NW];
+    extern __shared__ float plane_sm[];                  // TR: CB planes, Himg rows of (Wimg + 1) floats
     const int G = (C + CB - 1) / CB;
     const int total = gridDim.x, lin = blockIdx.x;      // XCD-aware order: the channel groups of one (o, b) share an L2
     const int per = total / 8, rem = total % 8, xcd = lin % 8, idx = lin / 8;
@@ -586,6 +590,22 @@ __global__ __launch_bounds__(NT, MINW) void ss2d_scan_rows_kernel(
     const float* xdb = (o ? xd1 + (int64_t)b * xbs1 : xd0 + (int64_t)b * xbs0);
     float* yb = (o ? y1 : y0) + (int64_t)b * C * L;
     const int lane = threadIdx.x & (BEM_WAVE - 1), wave = threadIdx.x / BEM_WAVE;
+    const bool via_lds = TR && o == 1;                   // uniform per workgroup
+    const int Wimg = TR ? L / Himg : 0, pitch = Wimg + 1, psz = Himg * pitch;
+    if (via_lds) {
+#pragma unroll
+        for (int ch = 0; ch < CB; ++ch) {
+            const float* src = xb + (int64_t)min(g * CB + ch, C - 1) * L;
+            float* pl = plane_sm + ch * psz;
+            for (int i = threadIdx.x * 4; i < L; i += NT * 4) {          // W % 4 == 0: the 4 pixels share a row
+                const float4 v = *reinterpret_cast<const float4*>(src + i);
+                const int row = i / Wimg, col = i - row * Wimg;
+                float* d = pl + row * pitch + col;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        }
+        __syncthreads();
+    }
     float4 y[CB][T];
     int slot = 0;
 #pragma unroll
@@ -606,12 +626,21 @@ __global__ __launch_bounds__(NT, MINW) void ss2d_scan_rows_kernel(
             const float4 Bq = *reinterpret_cast<const float4*>(xd + (int64_t)R * L + pos);
             const float4 Cq = *reinterpret_cast<const float4*>(xd + (int64_t)(R + 1) * L + pos);
             const float Bv[4] = {Bq.x, Bq.y, Bq.z, Bq.w}, Cv[4] = {Cq.x, Cq.y, Cq.z, Cq.w};
+            // column-major scan position pos = col * H + row (H % 4 == 0: the 4 positions share a column)
+            const int pcol = via_lds ? pos / Himg : 0, prow = via_lds ? pos - pcol * Himg : 0;
+            const int lofs = prow * pitch + pcol;
 #pragma unroll
             for (int ch = 0; ch < CB; ++ch) {
                 const int c = min(g * CB + ch, C - 1);          // a partial last group recomputes channel C - 1 (not stored)
                 __builtin_amdgcn_sched_barrier(0);
-                const float4 xq = *reinterpret_cast<const float4*>(xb + (int64_t)c * L + pos);
-                const float xv[4] = {xq.x, xq.y, xq.z, xq.w};
+                float xv[4];
+                if (via_lds) {
+                    const float* pl = plane_sm + ch * psz + lofs;
+                    xv[0] = pl[0]; xv[1] = pl[pitch]; xv[2] = pl[2 * pitch]; xv[3] = pl[3 * pitch];
+                } else {
+                    const float4 xq = *reinterpret_cast<const float4*>(xb + (int64_t)c * L + pos);
+                    xv[0] = xq.x; xv[1] = xq.y; xv[2] = xq.z; xv[3] = xq.w;
+                }
                 const float* wd = dtw + ((int64_t)kd * C + c) * R;
                 const float bias = dtb[kd * C + c], Ak = A[kd * C + c], Dk = Ds[kd * C + c];
                 float a[4], bb[4];
@@ -689,6 +718,32 @@ __global__ __launch_bounds__(NT, MINW) void ss2d_scan_rows_kernel(
                 asm volatile("" : "+v"(y[ch][k].x), "+v"(y[ch][k].y), "+v"(y[ch][k].z), "+v"(y[ch][k].w));
             }
         }
+    }
+    if (via_lds) {
+        __syncthreads();                                 // every read of the staged x planes is done
+#pragma unroll
+        for (int ch = 0; ch < CB; ++ch)
+#pragma unroll
+            for (int k = 0; k < T; ++k) {
+                const int pos = (k * NT + threadIdx.x) * 4, pcol = pos / Himg, prow = pos - pcol * Himg;
+                float* pl = plane_sm + ch * psz + prow * pitch + pcol;
+                pl[0] = y[ch][k].x; pl[pitch] = y[ch][k].y; pl[2 * pitch] = y[ch][k].z; pl[3 * pitch] = y[ch][k].w;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int ch = 0; ch < CB; ++ch) {
+            const int c = g * CB + ch;
+            if (c < C) {
+                const float* pl = plane_sm + ch * psz;
+                float* dst = yb + (int64_t)c * L;
+                for (int i = threadIdx.x * 4; i < L; i += NT * 4) {
+                    const int row = i / Wimg, col = i - row * Wimg;
+                    const float* sp = pl + row * pitch + col;
+                    *reinterpret_cast<float4*>(dst + i) = make_float4(sp[0], sp[1], sp[2], sp[3]);
+                }
+            }
+        }
+        return;
     }
 #pragma unroll
     for (int ch = 0; ch < CB; ++ch) {
@@ -869,8 +924,8 @@ extern "C" int bem_ss2d_scan_strided_f32(const float* x0, const float* x1, const
     const bool al = (((uintptr_t)x0 | (uintptr_t)x1 | (uintptr_t)xd0 | (uintptr_t)xd1 | (uintptr_t)y0 | (uintptr_t)y1) & 15) == 0;
     // channel-blocked whole-row forms for the plane sizes and dt_ranks of a 256x256 image (n_feat 40: C = 40 / 80 / 160)
     static const int variant = getenv("BEM_SCAN_VARIANT") ? atoi(getenv("BEM_SCAN_VARIANT")) : 1;
-#define BEM_SS2D_ROWS(NT, T, CB, RT, MW) do { ss2d_scan_rows_kernel<NT, T, CB, RT, MW><<<((C + CB - 1) / CB) * B * 2, NT, 0, s>>>( \
-        x0, x1, xd0, xd1, dtw, dtb, A, Ds, y0, y1, B, C, xbs0, xbs1); return bem_check_launch("ss2d_scan"); } while (0)
+#define BEM_SS2D_ROWS(NT, T, CB, RT, MW) do { ss2d_scan_rows_kernel<NT, T, CB, RT, MW, false><<<((C + CB - 1) / CB) * B * 2, NT, 0, s>>>( \
+        x0, x1, xd0, xd1, dtw, dtb, A, Ds, y0, y1, B, C, xbs0, xbs1, 0); return bem_check_launch("ss2d_scan"); } while (0)
     if (al && variant) {
         if (L == 1024 && R == 10) { if (variant == 2) BEM_SS2D_ROWS(256, 1, 2, 10, 6); else if (variant == 3) BEM_SS2D_ROWS(256, 1, 4, 10, 4); else BEM_SS2D_ROWS(256, 1, 4, 10, 5); }
         if (L == 4096 && R == 5) {
@@ -950,4 +1005,44 @@ extern "C" int bem_selective_scan_bwd_f32(const float* u, const float* delta, co
     selective_scan_bwd_kernel<256, 4><<<grid, 256, 0, s>>>(u, delta, A, Bm, Cm, D, delta_bias, dout, ws, du, ddelta, dA, dB, dC, dD,
                                                            ddelta_bias, dim, L, dstate, ngroups, delta_softplus);
     return bem_check_launch("selective_scan_bwd");
+}
+
+// Row-major in / row-major out form of the fused SS2D scan: x (B,C,H,W) serves both orientations, y0 and y1 are both
+// (B,C,H,W) row-major (y1 = directions 1 + 3, already transposed back).  Only the plane sizes of a 256x256 image with
+// their dt_ranks (L = 16384 / R = 3, 4096 / 5, 1024 / 10; H, W multiples of 4) -- bem_ss2d_scan_rm_supported tells.
+extern "C" int bem_ss2d_scan_rm_supported(int H, int W, int R) {
+    const int64_t L = (int64_t)H * W;
+    return H % 4 == 0 && W % 4 == 0 && ((L == 16384 && R == 3) || (L == 4096 && R == 5) || (L == 1024 && R == 10));
+}
+
+template <int NT, int T, int CB, int RT, int MW>
+static int launch_rows_tr(const float* x, const float* xd0, const float* xd1, const float* dtw, const float* dtb, const float* A,
+                          const float* Ds, float* y0, float* y1, int B, int C, int H, int W, int64_t xbs0, int64_t xbs1, hipStream_t s) {
+    const size_t lds = (size_t)CB * H * (W + 1) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ss2d_scan_rows_kernel<NT, T, CB, RT, MW, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+        attr_set = true;
+    }
+    ss2d_scan_rows_kernel<NT, T, CB, RT, MW, true><<<((C + CB - 1) / CB) * B * 2, NT, lds, s>>>(x, x, xd0, xd1, dtw, dtb, A, Ds, y0, y1, B, C,
+                                                                                               xbs0, xbs1, H);
+    return bem_check_launch("ss2d_scan_rm");
+}
+
+extern "C" int bem_ss2d_scan_rm_f32(const float* x, const float* xd0, const float* xd1, const float* dtw, const float* dtb,
+                                    const float* A, const float* Ds, float* y0, float* y1, int B, int C, int H, int W, int R,
+                                    int64_t xd0_bstride, int64_t xd1_bstride, void* stream) {
+    BEM_REQUIRE(x && xd0 && xd1 && dtw && dtb && A && Ds && y0 && y1, "ss2d_scan_rm: null tensor");
+    BEM_REQUIRE(B >= 0 && C > 0 && H > 0 && W > 0 && R >= 1 && (int64_t)B * C * 2 < (1ll << 31), "ss2d_scan_rm: bad shape");
+    BEM_REQUIRE(bem_ss2d_scan_rm_supported(H, W, R), "ss2d_scan_rm: unsupported plane %dx%d / dt_rank %d", H, W, R);
+    const int L = H * W;
+    const int64_t xbs0 = xd0_bstride ? xd0_bstride : (int64_t)2 * (R + 2) * L, xbs1 = xd1_bstride ? xd1_bstride : (int64_t)2 * (R + 2) * L;
+    BEM_REQUIRE(xbs0 >= (int64_t)2 * (R + 2) * L && xbs1 >= (int64_t)2 * (R + 2) * L && xbs0 % 4 == 0 && xbs1 % 4 == 0, "ss2d_scan_rm: x_dbl batch strides");
+    BEM_REQUIRE((((uintptr_t)x | (uintptr_t)xd0 | (uintptr_t)xd1 | (uintptr_t)y0 | (uintptr_t)y1) & 15) == 0, "ss2d_scan_rm: 16-byte alignment");
+    if (B == 0) return BEM_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (L == 16384) return launch_rows_tr<1024, 4, 1, 3, 8>(x, xd0, xd1, dtw, dtb, A, Ds, y0, y1, B, C, H, W, xbs0, xbs1, s);
+    if (L == 4096) return launch_rows_tr<512, 2, 2, 5, 6>(x, xd0, xd1, dtw, dtb, A, Ds, y0, y1, B, C, H, W, xbs0, xbs1, s);
+    return launch_rows_tr<256, 1, 4, 10, 5>(x, xd0, xd1, dtw, dtb, A, Ds, y0, y1, B, C, H, W, xbs0, xbs1, s);
 }

@@ -82,6 +82,15 @@ int bem_ss2d_scan_strided_f32(const float* x0, const float* x1, const float* xd0
                               float* y0, float* y1, int B, int C, int L, int R, int64_t xd0_bstride, int64_t xd1_bstride,
                               void* stream);
 
+/* Row-major in, row-major out: x (B,C,H,W) feeds both orientations and y1 (directions 1 + 3) comes back already in
+ * (B,C,H,W) order -- a workgroup of the column-major orientation stages its planes in LDS, so neither the transposed copy
+ * of x nor the transposed y exist in HBM.  xd1 stays in transposed pixel order (2 (R+2) small planes).  Plane sizes / ranks
+ * of a 256x256 image only: bem_ss2d_scan_rm_supported(H, W, R) != 0. */
+int bem_ss2d_scan_rm_supported(int H, int W, int R);
+int bem_ss2d_scan_rm_f32(const float* x, const float* xd0, const float* xd1, const float* dtw, const float* dtb,
+                         const float* A, const float* Ds, float* y0, float* y1, int B, int C, int H, int W, int R,
+                         int64_t xd0_bstride, int64_t xd1_bstride, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Pointwise (1x1) channel-mix GEMM on f32 MFMA with fused prologue / epilogue.  Replaces
  * Linear2d / nn.Conv2d(k=1) / LayerNorm2d+Linear2d chains (vmamba.py:42-63,123-133,702,715,1326-1334).

@@ -578,3 +578,22 @@ def test_gate_proj_vs_unfused_chain(ops, cfg):
         gg = F.gelu(t[:, :Hd]) * t[:, Hd:]
         ref.append(F.conv2d(gg, (wo[i] if per_b else wo)[:, :, None, None], bo[i] if per_b else bo) + res[i:i + 1])
     close(y, torch.cat(ref), 1e-4, 2e-5, f"gate_proj vs torch {cfg}")
+
+
+@pytest.mark.parametrize("shape", [(2, 40, 128, 128, 3), (1, 80, 64, 64, 5), (2, 160, 32, 32, 10), (1, 6, 16, 64, 10), (1, 5, 256, 16, 5)])
+def test_ss2d_scan_row_major_form(ops, shape):
+    """bem_ss2d_scan_rm (orientation 1 staged through LDS, y1 row-major) against the transposed-tensor form: identical
+    arithmetic, so the results must agree to the last bit; non-square planes and a partial channel group included."""
+    B, C, H, W, R = shape
+    g = torch.Generator().manual_seed(H + C)
+    L = H * W
+    x = dev(torch.randn(B, C, H, W, generator=g))
+    xd0, xd1 = dev(torch.randn(B, 2, R + 2, L, generator=g)), dev(torch.randn(B, 2, R + 2, L, generator=g))
+    dtw, dtb = dev(torch.randn(4, C, R, generator=g) * 0.3), dev(torch.randn(4, C, generator=g) - 2)
+    A, Ds = dev(-torch.rand(4 * C, generator=g)), dev(torch.randn(4 * C, generator=g))
+    assert ops.ss2d_scan_rm_supported(H, W, R)
+    y0, y1 = ops.ss2d_scan_rm(x, xd0, xd1, dtw, dtb, A, Ds)
+    xT = ops.transpose_planes(x)
+    r0, r1 = ops.ss2d_scan(x.view(B, C, L), xT.view(B, C, L), xd0, xd1, dtw, dtb, A, Ds)
+    assert torch.equal(y0.view(B, C, L), r0)
+    assert torch.equal(y1, ops.transpose_planes(r1.view(B, C, W, H)))
