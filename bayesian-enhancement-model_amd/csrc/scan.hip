@@ -591,7 +591,10 @@ __global__ __launch_bounds__(NT, MINW) void ss2d_scan_rows_kernel(
     float* yb = (o ? y1 : y0) + (int64_t)b * C * L;
     const int lane = threadIdx.x & (BEM_WAVE - 1), wave = threadIdx.x / BEM_WAVE;
     const bool via_lds = TR && o == 1;                   // uniform per workgroup
-    const int Wimg = TR ? L / Himg : 0, pitch = Wimg + 1, psz = Himg * pitch;
+    // LDS plane layout: element (row, col) at (row >> 2) * (4 pitch + 1) + (row & 3) * pitch + col, pitch = W + 1.  A lane reads
+    // 4 consecutive rows of one column (rows 4n .. 4n + 3): the extra +1 per group of 4 rows makes the lane stride
+    // 4 pitch + 1 (odd), so the 32 lanes of a half-wave hit 32 different banks.
+    const int Wimg = TR ? L / Himg : 0, pitch = Wimg + 1, gpitch = 4 * pitch + 1, psz = (Himg >> 2) * gpitch;
     if (via_lds) {
 #pragma unroll
         for (int ch = 0; ch < CB; ++ch) {
@@ -600,7 +603,7 @@ __global__ __launch_bounds__(NT, MINW) void ss2d_scan_rows_kernel(
             for (int i = threadIdx.x * 4; i < L; i += NT * 4) {          // W % 4 == 0: the 4 pixels share a row
                 const float4 v = *reinterpret_cast<const float4*>(src + i);
                 const int row = i / Wimg, col = i - row * Wimg;
-                float* d = pl + row * pitch + col;
+                float* d = pl + (row >> 2) * gpitch + (row & 3) * pitch + col;
                 d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
             }
         }
@@ -628,7 +631,7 @@ __global__ __launch_bounds__(NT, MINW) void ss2d_scan_rows_kernel(
             const float Bv[4] = {Bq.x, Bq.y, Bq.z, Bq.w}, Cv[4] = {Cq.x, Cq.y, Cq.z, Cq.w};
             // column-major scan position pos = col * H + row (H % 4 == 0: the 4 positions share a column)
             const int pcol = via_lds ? pos / Himg : 0, prow = via_lds ? pos - pcol * Himg : 0;
-            const int lofs = prow * pitch + pcol;
+            const int lofs = (prow >> 2) * gpitch + pcol;          // prow % 4 == 0
 #pragma unroll
             for (int ch = 0; ch < CB; ++ch) {
                 const int c = min(g * CB + ch, C - 1);          // a partial last group recomputes channel C - 1 (not stored)
@@ -726,7 +729,7 @@ __global__ __launch_bounds__(NT, MINW) void ss2d_scan_rows_kernel(
 #pragma unroll
             for (int k = 0; k < T; ++k) {
                 const int pos = (k * NT + threadIdx.x) * 4, pcol = pos / Himg, prow = pos - pcol * Himg;
-                float* pl = plane_sm + ch * psz + prow * pitch + pcol;
+                float* pl = plane_sm + ch * psz + (prow >> 2) * gpitch + pcol;
                 pl[0] = y[ch][k].x; pl[pitch] = y[ch][k].y; pl[2 * pitch] = y[ch][k].z; pl[3 * pitch] = y[ch][k].w;
             }
         __syncthreads();
@@ -738,7 +741,7 @@ __global__ __launch_bounds__(NT, MINW) void ss2d_scan_rows_kernel(
                 float* dst = yb + (int64_t)c * L;
                 for (int i = threadIdx.x * 4; i < L; i += NT * 4) {
                     const int row = i / Wimg, col = i - row * Wimg;
-                    const float* sp = pl + row * pitch + col;
+                    const float* sp = pl + (row >> 2) * gpitch + (row & 3) * pitch + col;
                     *reinterpret_cast<float4*>(dst + i) = make_float4(sp[0], sp[1], sp[2], sp[3]);
                 }
             }
@@ -1018,7 +1021,7 @@ extern "C" int bem_ss2d_scan_rm_supported(int H, int W, int R) {
 template <int NT, int T, int CB, int RT, int MW>
 static int launch_rows_tr(const float* x, const float* xd0, const float* xd1, const float* dtw, const float* dtb, const float* A,
                           const float* Ds, float* y0, float* y1, int B, int C, int H, int W, int64_t xbs0, int64_t xbs1, hipStream_t s) {
-    const size_t lds = (size_t)CB * H * (W + 1) * sizeof(float);
+    const size_t lds = (size_t)CB * (H / 4) * (4 * (W + 1) + 1) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ss2d_scan_rows_kernel<NT, T, CB, RT, MW, true>),
