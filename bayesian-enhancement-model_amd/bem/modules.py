@@ -216,7 +216,10 @@ class _BayesBase(nn.Module):
                 eb = ctx.eps[self.module_path + ".bias"].contiguous()
         if packed_mk is not None and ops.USE_X6:
             # GEMM weights go straight into operand order (same Philox stream ids, same values as sample-then-pack)
-            w = ops.bnn_sample_packed(self.mu_weight.detach(), self.rho_weight.detach(), ns, packed_mk[0], packed_mk[1], ew, ctx.seed, ctx.next_stream())
+            # sigma = log1p(exp(rho)) once per weight version (one launch of the sampler with mu = 0, eps = 1), not once per sample
+            rho = self.rho_weight
+            sigma = self._cache.get("sigma", [rho], lambda: ops.bnn_sample(torch.zeros_like(rho), rho.detach(), 1, torch.ones_like(rho))[0])
+            w = ops.bnn_sample_packed(self.mu_weight.detach(), sigma, ns, packed_mk[0], packed_mk[1], ew, ctx.seed, ctx.next_stream(), sigma_given=True)
         else:
             w = ops.bnn_sample(self.mu_weight.detach(), self.rho_weight.detach(), ns, ew, ctx.seed, ctx.next_stream())
         b = None

@@ -604,13 +604,14 @@ def bnn_sample(mu, rho, nsets, eps=None, seed=0, stream_id=0):
     return out
 
 
-def bnn_sample_packed(mu, rho, nsets, M, K, eps=None, seed=0, stream_id=0):
-    """bnn_sample + pack_pw_weight(x6) in one kernel: (nsets, packed(M, K)) GEMM weights of a Bayesian 1x1 layer."""
+def bnn_sample_packed(mu, rho, nsets, M, K, eps=None, seed=0, stream_id=0, sigma_given=False):
+    """bnn_sample + pack_pw_weight(x6) in one kernel: (nsets, packed(M, K)) GEMM weights of a Bayesian 1x1 layer.
+    sigma_given: ``rho`` already holds sigma = log1p(exp(rho)) (it does not depend on the sample)."""
     _chk(mu, "mu"); _chk(rho, "rho"); _chk(eps, "eps", optional=True)
     if mu.numel() != M * K or rho.numel() != M * K or (eps is not None and eps.numel() != nsets * M * K):
         raise ValueError("bnn_sample_packed: shapes")
     out = torch.empty(nsets, packed_elems(M, K, True), device=mu.device, dtype=mu.dtype)
-    check(lib().bem_bnn_sample_pack_x6(_p(mu), _p(rho), _p(eps), _p(out), nsets, M, K, seed, stream_id, _stream()), "bnn_sample_pack_x6")
+    check(lib().bem_bnn_sample_pack_x6(_p(mu), _p(rho), _p(eps), _p(out), nsets, M, K, seed, stream_id, int(bool(sigma_given)), _stream()), "bnn_sample_pack_x6")
     out._bem_mk = (M, K)
     return out
 

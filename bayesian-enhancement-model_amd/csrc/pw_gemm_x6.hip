@@ -572,7 +572,8 @@ __global__ void pack_x6_kernel(const float* __restrict__ W, u32x4* __restrict__ 
 // with the sampler's own Philox stream (element index i = set*M*K + row*K + k, as bem_bnn_sample_f32 numbers it), split
 // and stored like pack_x6_kernel does -- the natural-order copy (one write + one read per weight and sample) is skipped.
 __global__ void sample_pack_x6_kernel(const float* __restrict__ mu, const float* __restrict__ rho, const float* __restrict__ eps_in,
-                                      u32x4* __restrict__ Wp, int M, int K, int MT, int KB, int64_t total, uint64_t seed, uint64_t stream_id) {
+                                      u32x4* __restrict__ Wp, int M, int K, int MT, int KB, int64_t total, uint64_t seed, uint64_t stream_id,
+                                      int sigma_given) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int lane = (int)(i & 63);
@@ -598,7 +599,8 @@ __global__ void sample_pack_x6_kernel(const float* __restrict__ mu, const float*
             const float zsel = off == 0 ? z[e >> 2][e & 3] : off == 1 ? z[(e + 1) >> 2][(e + 1) & 3]
                              : off == 2 ? z[(e + 2) >> 2][(e + 2) & 3] : z[(e + 3) >> 2][(e + 3) & 3];
             const float eps = eps_in ? eps_in[gi] : zsel;
-            v[e] = mu[idx] + log1pf(expf(rho[idx])) * eps;
+            // sigma = log1p(exp(rho)) does not depend on the sample: callers that draw many sets pass it precomputed
+            v[e] = mu[idx] + (sigma_given ? rho[idx] : log1pf(expf(rho[idx]))) * eps;
         }
     }
     u32x4 h, m, l;
@@ -610,7 +612,7 @@ __global__ void sample_pack_x6_kernel(const float* __restrict__ mu, const float*
 }  // namespace
 
 extern "C" int bem_bnn_sample_pack_x6(const float* mu, const float* rho, const float* eps_in, float* Wp, int nsets, int M, int K,
-                                      uint64_t seed, uint64_t stream_id, void* stream) {
+                                      uint64_t seed, uint64_t stream_id, int sigma_given, void* stream) {
     BEM_REQUIRE(mu && rho && Wp, "bnn_sample_pack_x6: null tensor");
     BEM_REQUIRE(nsets >= 0 && M > 0 && K > 0, "bnn_sample_pack_x6: bad shape");
     BEM_REQUIRE(((uintptr_t)Wp & 15) == 0, "bnn_sample_pack_x6: output must be 16-byte aligned");
@@ -618,7 +620,7 @@ extern "C" int bem_bnn_sample_pack_x6(const float* mu, const float* rho, const f
     const int MT = cdiv(M, 32), KB = cdiv(K, 16);
     const int64_t total = (int64_t)nsets * MT * KB * 64;
     sample_pack_x6_kernel<<<(unsigned)cdiv64(total, 256), 256, 0, (hipStream_t)stream>>>(mu, rho, eps_in, reinterpret_cast<u32x4*>(Wp), M, K, MT, KB,
-                                                                                       total, seed, stream_id);
+                                                                                       total, seed, stream_id, sigma_given);
     return bem_check_launch("bnn_sample_pack_x6");
 }
 

@@ -133,7 +133,7 @@ int64_t bem_pw_x6_packed_elems(int M, int K);
  * sets w = mu + log1p(exp(rho)) * eps written straight in x6 operand order; eps (nsets, M, K) injected or NULL = the
  * sampler's Philox draws for (seed, stream_id) -- identical values to sampling first and packing afterwards. */
 int bem_bnn_sample_pack_x6(const float* mu, const float* rho, const float* eps, float* Wp, int nsets, int M, int K,
-                           uint64_t seed, uint64_t stream_id, void* stream);
+                           uint64_t seed, uint64_t stream_id, int sigma_given, void* stream);   /* sigma_given: rho already holds log1p(exp(rho)) */
 
 /* ---------------------------------------------------------------------------------------------
  * Fused gdMlp block (vmamba.py:116-133 + the norm2 / residual around it, vmamba.py:1330-1333):

@@ -538,6 +538,9 @@ def test_bnn_sample_packed_equals_sample_then_pack(ops):
         a = ops.bnn_sample_packed(dev(mu), dev(rho), ns, M, K, e, seed=11, stream_id=5)
         b = ops.pack_pw_weight(ops.bnn_sample(dev(mu), dev(rho), ns, e, seed=11, stream_id=5), x6=True)
         assert a.shape == b.shape and torch.equal(a.view(torch.int32), b.view(torch.int32))
+        sigma = ops.bnn_sample(dev(torch.zeros_like(mu)), dev(rho), 1, dev(torch.ones_like(mu)))[0]     # log1p(exp(rho)) by the sampler itself
+        c = ops.bnn_sample_packed(dev(mu), sigma, ns, M, K, e, seed=11, stream_id=5, sigma_given=True)
+        assert torch.equal(a.view(torch.int32), c.view(torch.int32))
 
 
 @pytest.mark.parametrize("cfg", [(40, 320, False), (40, 40, True), (160, 40, True)])
