@@ -1,6 +1,28 @@
-"""Thin model wrapper: device placement + checkpoint loading (basicsr/models/base_model.py:89-103,283-343).
-Optimisers, schedulers, validation and saving are outside the hot path."""
+"""Model wrapper base (basicsr/models/base_model.py): device placement, checkpoint loading (:283-343), schedulers (:124-168),
+learning-rate update with linear warm-up (:209-230), loss-dict reduction (:396-421)."""
+from collections import OrderedDict
+
 import torch
+
+from basicsr.models import lr_scheduler
+
+
+class _LazyLog(OrderedDict):
+    """log_dict whose values are device scalars until somebody reads them (the reference calls .item() inside the step, one host
+    synchronisation per iteration; here the step stays asynchronous and the read pays it)."""
+
+    def __getitem__(self, k):
+        v = super().__getitem__(k)
+        if torch.is_tensor(v):
+            v = float(v.mean().item())
+            super().__setitem__(k, v)
+        return v
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def values(self):
+        return [self[k] for k in self.keys()]
 
 
 class BaseModel:
@@ -8,12 +30,63 @@ class BaseModel:
         self.opt = opt
         self.device = torch.device("cuda" if opt.get("num_gpu", 1) != 0 and torch.cuda.is_available() else "cpu")
         self.is_train = opt.get("is_train", False)
+        self.schedulers, self.optimizers = [], []
+        self.log_dict = OrderedDict()
 
     def model_to_device(self, net):
         return net.to(self.device)
+
+    def get_bare_model(self, net):
+        return net.module if hasattr(net, "module") else net
 
     def load_network(self, net, load_path, strict=True, param_key="params"):
         ck = torch.load(load_path, map_location="cpu", weights_only=True)
         sd = ck[param_key] if param_key is not None and param_key in ck else ck
         sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
         net.load_state_dict(sd, strict=strict)
+
+    # -- training-side helpers -------------------------------------------------------------------------------------
+    def setup_schedulers(self):
+        sch = dict(self.opt["train"]["scheduler"])
+        kind = sch.pop("type")
+        if kind == "CosineAnnealingRestartCyclicLR":
+            for o in self.optimizers:
+                self.schedulers.append(lr_scheduler.CosineAnnealingRestartCyclicLR(o, **sch))
+        elif kind == "TrueCosineAnnealingLR":
+            for o in self.optimizers:
+                self.schedulers.append(torch.optim.lr_scheduler.CosineAnnealingLR(o, **sch))
+        else:
+            raise NotImplementedError(f"Scheduler {kind} is not implemented yet.")
+
+    def _get_init_lr(self):
+        return [[g["initial_lr"] for g in o.param_groups] for o in self.optimizers]
+
+    def _set_lr(self, lr_groups_l):
+        for o, lrs in zip(self.optimizers, lr_groups_l):
+            for g, lr in zip(o.param_groups, lrs):
+                g["lr"] = lr
+
+    def update_learning_rate(self, current_iter, warmup_iter=-1):
+        if current_iter > 1:
+            for s in self.schedulers:
+                s.step()
+        if current_iter < warmup_iter:
+            self._set_lr([[v / warmup_iter * current_iter for v in g] for g in self._get_init_lr()])
+
+    def get_current_learning_rate(self):
+        return [g["lr"] for g in self.optimizers[0].param_groups]
+
+    def get_current_log(self):
+        return self.log_dict
+
+    def reduce_loss_dict(self, loss_dict):
+        """Average over ranks when distributed (one reduce of the stacked scalars to rank 0, base_model.py:405-415)."""
+        with torch.no_grad():
+            if self.opt.get("dist"):
+                keys = list(loss_dict)
+                losses = torch.stack([loss_dict[k].reshape(()) for k in keys], 0)
+                torch.distributed.reduce(losses, dst=0)
+                if self.opt.get("rank", 0) == 0:
+                    losses /= self.opt["world_size"]
+                loss_dict = {k: v for k, v in zip(keys, losses)}
+            return _LazyLog((k, v.detach()) for k, v in loss_dict.items())

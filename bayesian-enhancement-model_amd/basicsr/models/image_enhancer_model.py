@@ -1,7 +1,19 @@
-"""ImageEnhancer (basicsr/models/image_enhancer_model.py:28-63): Stage-II net wrapper."""
+"""ImageEnhancer (basicsr/models/image_enhancer_model.py): Stage-II net wrapper -- build / load (:28-63) and the training step
+(:64-128 settings, :130-148 feed_train_data, :165-216 optimize_parameters).
+
+The step runs entirely on the HIP path: condition upsample + concat (bem.ops), forward / backward (bem.autograd), global-norm clip +
+AdamW on one flat buffer (bem.train.BemAdamW), with no host synchronisation inside ``optimize_parameters`` -- loss values and the
+gradient norm come back as device scalars (read them when logging).  AMP (`use_amp`) is not offered: the path is f32."""
+from collections import OrderedDict
+
+import torch
+
 from basicsr.archs import build_network
+from basicsr.losses import build_loss
 from basicsr.models.base_model import BaseModel
 from basicsr.utils.registry import MODEL_REGISTRY
+from bem import ops
+from bem.train import BemAdamW
 
 
 @MODEL_REGISTRY.register()
@@ -13,5 +25,78 @@ class ImageEnhancer(BaseModel):
         path = opt["path"].get("pretrain_network_g")
         if path is not None:
             self.load_network(self.net_g, path, opt["path"].get("strict_load_g", True), opt["path"].get("param_key", "params"))
+        self.mixing_flag = False
+        self.mask = None
         if self.is_train:
-            raise NotImplementedError("the Stage-II training step (backward kernels) is SURVEY.md row A10, not built this round")
+            if opt.get("use_amp") or opt.get("train", {}).get("use_amp"):
+                raise NotImplementedError("ImageEnhancer: use_amp is not available on the f32 HIP path")
+            if opt["train"].get("mixing_augs", {}).get("mixup", False):
+                raise NotImplementedError("ImageEnhancer: mixup augmentation is host-side data preparation outside the hot path")
+            self.init_training_settings()
+
+    # ---------------------------------------------------------------------------------------------------------------
+    def init_training_settings(self):
+        self.net_g.train()
+        train_opt = self.opt["train"]
+        self.ema_decay = train_opt.get("ema_decay", 0)
+        if self.ema_decay > 0:
+            raise NotImplementedError("ImageEnhancer: ema_decay > 0 (a second, averaged copy of the net) is not used by the shipped option files")
+        self.cri_pix = build_loss(train_opt["pixel_opt"]).to(self.device) if train_opt.get("pixel_opt") else None
+        self.cri_perceptual = build_loss(train_opt["perceptual_opt"]).to(self.device) if train_opt.get("perceptual_opt") else None
+        if self.cri_pix is None and self.cri_perceptual is None:
+            raise ValueError("Both pixel and perceptual losses are None.")
+        self.optimizers, self.schedulers = [], []
+        self.setup_optimizers()
+        self.setup_schedulers()
+
+    def setup_optimizers(self):
+        train_opt = self.opt["train"]
+        normal, custom = [], []
+        for k, v in self.net_g.named_parameters():
+            if v.requires_grad:
+                (custom if "impfusion" in k else normal).append(v)
+        groups = [{"params": normal, "lr_mult": 1, "name": "normal_params"},
+                  {"params": custom, "lr_mult": 1, "decay_mult": 0, "name": "custom_params"}]
+        cfg = dict(train_opt["optim_g"])
+        kind = cfg.pop("type")
+        if kind != "AdamW":
+            raise NotImplementedError(f"optimizer {kind} is not supperted yet.")      # the shipped option files use AdamW
+        self.optimizer_g = BemAdamW(groups, **cfg)
+        self.optimizers.append(self.optimizer_g)
+
+    def feed_train_data(self, data):
+        dev = self.device
+        self.lq = data["lq"].to(dev)
+        self.gt = data["gt"].to(dev) if "gt" in data else None
+        self.mask = data["mask"].to(dev) if "mask" in data else None
+        cond = self.opt["condition"]
+        if cond["type"] == "histogram":
+            raise NotImplementedError("condition type 'histogram' is not used by the shipped option files")
+        gd = data["gt_down"].to(dev).contiguous()
+        nl = cond.get("noise_level", 0)
+        # conds = gt_down + randn_like(gt_down) * noise_level  (:143-148); the draw comes from the device Philox stream
+        self._cond_calls = getattr(self, "_cond_calls", 0) + 1
+        self.conds = ops.add(gd, ops.randn(tuple(gd.shape), dev, int(self.opt.get("manual_seed", 0) or 0), (1 << 41) + self._cond_calls), nl) if nl else gd
+
+    feed_data = feed_train_data
+
+    def optimize_parameters(self, current_iter):
+        self.optimizer_g.zero_grad()
+        s = self.opt["condition"].get("scale_down", 0) + self.opt["condition"].get("hist_patch_size", 0)
+        B, _, H, W = self.lq.shape
+        x = torch.empty(B, 6, H, W, device=self.lq.device, dtype=torch.float32)
+        ops.copy_channels(self.lq.contiguous(), x, 0)
+        ops.bilinear_up(self.conds, s, dst=x, dst_c0=3)                # F.interpolate(conds, scale_factor=s, 'bilinear') into channels 3..5
+        _, preds = self.net_g(x, mask=None)                           # the Decomp* archs ignore the MIM mask (DDWavelet_arch.py:301)
+        loss_dict = OrderedDict()
+        if self.cri_pix is None:
+            raise NotImplementedError("ImageEnhancer: the pixel loss is the only loss on the HIP path")
+        l_total = l_pix = self.cri_pix(preds, self.gt)
+        w = self.opt["train"]["pixel_opt"].get("loss_weight", 1)
+        loss_dict["l_pix"] = l_pix.detach() if w == 1 else l_pix.detach() / w
+        l_total.backward()
+        mgn = self.opt["train"].get("max_grad_norm")
+        total_norm = self.optimizer_g.clip_grad_norm_(mgn if mgn else float("inf"))
+        self.optimizer_g.step()
+        self.log_dict = self.reduce_loss_dict(loss_dict)
+        return total_norm

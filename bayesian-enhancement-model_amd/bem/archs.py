@@ -15,8 +15,9 @@ import os
 import torch
 import torch.nn as nn
 
+from . import autograd as ag
 from . import ops
-from .modules import (Conv2dK, ConvT2x2, LayerNorm2d, PwConv2d, VSSBlock, _Cache, _need_cuda, make_vss_level,
+from .modules import (Conv2dK, ConvT2x2, LayerNorm2d, PwConv2d, VSSBlock, _Cache, _need_cuda, grad_mode, make_vss_level,
                       set_module_paths)
 from .native import BemNativeError
 
@@ -218,28 +219,36 @@ class DecompDualBranchDDWavelet(nn.Module):
             sk = []
             for i in range(self.num_levels - 1):
                 f = getattr(self, f"encoders_{br}")[i](f)
-                sk.append(f)
+                f, s_ = ag.fork(f)          # two consumers (down layer, decoder skip): their gradients meet in bem_add_f32
+                sk.append(s_)
                 f = getattr(self, f"down_layers_{br}")[i](f)
             feats[br], skips[br] = f, sk
         fused = self.bottleneck_fuse(feats["Q1"], x2=feats["Q2"], in_mode=2)
         fused = self.bottleneck_block(fused)
         outs = []
-        for br in ("Q1", "Q2"):
-            f = getattr(self, f"bottleneck_to_{br}")(fused)
+        for br, fz in zip(("Q1", "Q2"), ag.fork(fused)):
+            f = getattr(self, f"bottleneck_to_{br}")(fz)
             for j, dec in enumerate(getattr(self, f"decoders_{br}")):
                 f = dec["up"](f)
                 f = dec["fuse"](f, x2=skips[br][self.num_levels - 2 - j], in_mode=2)
                 f = dec["block"](f)
             outs.append(getattr(self, f"proj_{br}")(f))
+        if outs[0].requires_grad or outs[1].requires_grad:
+            return ag.IwtHamiltonFn.apply(outs[0], outs[1])
         return ops.iwt_hamilton(outs[0], outs[1])
 
     def forward(self, x, mask=None):
+        """Inference: kernels only, nothing recorded.  ``train()`` mode with autograd enabled (image_enhancer_model.py:165-216):
+        the frozen decomposition still runs without a graph (DDWavelet_arch.py:307), the U-Nets record bem.autograd nodes."""
         _need_cuda(x)
+        train = grad_mode(self)
         with torch.no_grad():
             x = x.contiguous()
             if x.shape[1] != 6:
                 raise ValueError("DecompDualBranchDDWavelet expects 6 input channels (image || condition)")
-            out = self.forward_decomposed(self.decomp(x, 0), self.decomp(x, 3))
+            d_img, d_cond = self.decomp(x, 0), self.decomp(x, 3)
+        with torch.enable_grad() if train else torch.no_grad():
+            out = self.forward_decomposed(d_img, d_cond)
         return [x, out]
 
 

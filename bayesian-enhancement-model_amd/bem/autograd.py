@@ -1,0 +1,352 @@
+"""Training path of the Stage-II nets: ``torch.autograd.Function``s whose forward AND backward are sequences of hand-written
+gfx950 kernels (bem.ops).  torch's autograd engine only walks the graph; no gradient is computed by a torch op.
+
+What is differentiated: ``DecompDualBranchDDWavelet.forward`` and its siblings
+(basicsr/archs/DecompDualBranchDDWavelet_arch.py:301-369) as driven by ``ImageEnhancer.optimize_parameters``
+(basicsr/models/image_enhancer_model.py:165-216): Hamilton product / IWT, dense 3x3 and 4x4-stride-2 convolutions,
+ConvTranspose2d(2,2), 1x1 fuse layers and the 18 ``VSSBlock``s (vmamba.py:1319-1334: LayerNorm2d, Linear2d, depthwise 3x3 +
+SiLU, the four-direction selective scan with x_proj / dt_proj -- the reference's CrossScanF / SelectiveScanCuda /
+CrossMergeF backward, csm_triton.py:207-273, csms6s.py:95-113 -- and the gdMlp).
+
+Parameter gradients are accumulated by the kernels straight into ``param.grad`` (allocated zero-filled on first use, or a view
+of the flat buffer of ``bem.train.FlatParams``); the Functions return ``None`` for parameter inputs.  Use ``loss.backward()``
+(as the reference's training step does) -- ``torch.autograd.grad`` with respect to parameters is not supported.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+from .native import check, lib
+
+WEIGHT_EPOCH = ops.WEIGHT_EPOCH      # see bem.ops: bumped by optimizer steps that rewrite parameters in place
+
+
+class _Derived:
+    """Cache of tensors derived from parameters, valid for one weight epoch and parameter version."""
+
+    def __init__(self):
+        self.d = {}
+
+    def get(self, key, srcs, fn):
+        sig = (WEIGHT_EPOCH[0],) + tuple((t.data_ptr(), t._version) for t in srcs)
+        hit = self.d.get(key)
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        with torch.no_grad():
+            val = fn()
+        self.d[key] = (sig, val)
+        return val
+
+
+def _derived(holder) -> _Derived:
+    c = getattr(holder, "_bem_derived", None)
+    if c is None:
+        c = _Derived()
+        object.__setattr__(holder, "_bem_derived", c)
+    return c
+
+
+def grad_of(p: torch.Tensor) -> torch.Tensor:
+    """The buffer the kernels accumulate this parameter's gradient into."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+    elif not p.grad.is_contiguous():
+        raise RuntimeError("bem.autograd: parameter .grad must be contiguous")
+    return p.grad
+
+
+def _pack(holder, key, srcs, make):
+    """pack_pw_weight of ``make()`` (an (M,K) matrix), cached on ``holder``."""
+    return _derived(holder).get(key, srcs, lambda: ops.pack_pw_weight(make().contiguous()))
+
+
+def _w2d(w):
+    return w.detach().reshape(w.shape[0], -1)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# small nodes
+# ------------------------------------------------------------------------------------------------------------------
+class ForkFn(Function):
+    """A tensor with two consumers: the two incoming gradients are summed by bem_add_f32 (not by the engine's own add)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        if g1 is None:
+            return g2
+        if g2 is None:
+            return g1
+        return ops.add(g1.contiguous(), g2.contiguous())
+
+
+def fork(x):
+    return ForkFn.apply(x) if x.requires_grad else (x, x)
+
+
+class L1LossFn(Function):
+    """basicsr/losses/losses.py L1Loss(loss_weight, reduction='mean')."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, weight):
+        pred, gt = pred.contiguous(), gt.contiguous()
+        ctx.save_for_backward(pred, gt)
+        ctx.weight = weight
+        return ops.l1_loss(pred, gt, weight).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, gt = ctx.saved_tensors
+        # g = dL/dloss as a device scalar (1.0 in the reference's step; an AMP scaler passes its scale): folded into the kernel
+        return ops.l1_loss_bwd(pred, gt, ctx.weight, g.reshape(1).contiguous().float()), None, None
+
+
+def l1_loss(pred, gt, weight=1.0):
+    return L1LossFn.apply(pred, gt, float(weight))
+
+
+class IwtHamiltonFn(Function):
+    @staticmethod
+    def forward(ctx, q1w, q2w):
+        q1w, q2w = q1w.contiguous(), q2w.contiguous()
+        ctx.save_for_backward(q1w, q2w)
+        return ops.iwt_hamilton(q1w, q2w)
+
+    @staticmethod
+    def backward(ctx, dout):
+        q1w, q2w = ctx.saved_tensors
+        return ops.iwt_hamilton_bwd(q1w, q2w, dout.contiguous())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# 1x1 layers without a LayerNorm prologue (fuse, bottleneck_fuse, bottleneck_to_Q*)
+# ------------------------------------------------------------------------------------------------------------------
+class PwFn(Function):
+    @staticmethod
+    def forward(ctx, x1, x2, weight, bias, holder):
+        x1 = x1.contiguous()
+        M = weight.shape[0]
+        Wp, _ = holder.gemm_weights(x1.shape[0])
+        if x2 is not None:
+            x2 = x2.contiguous()
+            out = ops.pw_gemm(x1, Wp, M, x2=x2, in_mode=2, bias=None if bias is None else bias.detach())
+        else:
+            out = ops.pw_gemm(x1, Wp, M, bias=None if bias is None else bias.detach())
+        ctx.save_for_backward(x1, x2)
+        ctx.holder, ctx.weight, ctx.bias = holder, weight, bias
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x1, x2 = ctx.saved_tensors
+        dout = dout.contiguous()
+        w, b, h = ctx.weight, ctx.bias, ctx.holder
+        C1 = x1.shape[1]
+        ops.pw_wgrad_(dout, x1, grad_of(w), x2=x2, dbias=None if b is None else grad_of(b))
+        w2 = _w2d(w)
+        dx1 = dx2 = None
+        if ctx.needs_input_grad[0]:
+            dx1 = ops.pw_gemm(dout, _pack(h, "T1", [w], lambda: w2[:, :C1].t()), C1)
+        if x2 is not None and ctx.needs_input_grad[1]:
+            C2 = x2.shape[1]
+            dx2 = ops.pw_gemm(dout, _pack(h, "T2", [w], lambda: w2[:, C1:].t()), C2)
+        return dx1, dx2, None, None, None
+
+
+class ConvT2x2Fn(Function):
+    """nn.ConvTranspose2d(C, C/2, 2, 2): forward = 1x1 GEMM to 4*Co rows + 2x2 scatter (modules.ConvT2x2)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, holder):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        ctx.holder, ctx.weight, ctx.bias = holder, weight, bias
+        return holder._forward_nograd(x)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x,) = ctx.saved_tensors
+        w, b, h = ctx.weight, ctx.bias, ctx.holder
+        Cin, Co = w.shape[0], w.shape[1]
+        dy4 = ops.pixel_unshuffle2(dout.contiguous())                 # (B, 4 Co, H, W), channel = co*4 + dy*2 + dx
+        ops.pw_wgrad_(x, dy4, grad_of(w))                            # (Cin, Co*4) = weight.grad's own layout
+        ops.channel_sum_(dout, grad_of(b))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.pw_gemm(dy4, _pack(h, "T", [w], lambda: w.detach().reshape(Cin, 4 * Co)), Cin)
+        return dx, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# dense convolutions (3x3 stride 1 pad 1; 4x4 stride 2 pad 1)
+# ------------------------------------------------------------------------------------------------------------------
+def _wflip3(w):
+    return w.detach().flip(2, 3).transpose(0, 1).contiguous()          # (Cin, Cout, 3, 3): correlation with the flipped kernel
+
+
+def _wT4(w):
+    """Input gradient of the 4x4 stride-2 pad-1 convolution as a 3x3 convolution over dout producing 4*Cin phase channels
+    (PixelShuffle order ci*4 + py*2 + px), then pixel_shuffle2."""
+    w = w.detach()
+    Co, Ci = w.shape[0], w.shape[1]
+    w3 = torch.zeros(Ci, 2, 2, Co, 3, 3, device=w.device, dtype=w.dtype)
+    taps = {0: ((0, 1), (-1, 3)), 1: ((1, 0), (0, 2))}                 # phase -> ((offset, kernel index), ...)
+    for py in (0, 1):
+        for di, ky in taps[py]:
+            for px in (0, 1):
+                for dj, kx in taps[px]:
+                    w3[:, py, px, :, di + 1, dj + 1] = w[:, :, ky, kx].t()
+    return w3.reshape(Ci * 4, Co, 3, 3).contiguous()
+
+
+class Conv2dFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, holder, cin_slice):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        ctx.holder, ctx.weight, ctx.bias, ctx.cin_slice = holder, weight, bias, cin_slice
+        return ops.conv2d(x, weight.detach(), None if bias is None else bias.detach(), stride=holder.stride[0], pad=holder.padding[0],
+                          cin_slice=cin_slice)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x,) = ctx.saved_tensors
+        w, b, h = ctx.weight, ctx.bias, ctx.holder
+        dout = dout.contiguous()
+        s, p = h.stride[0], h.padding[0]
+        ops.conv_wgrad_(dout, x, grad_of(w), None if b is None else grad_of(b), stride=s, pad=p, cin_slice=ctx.cin_slice)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if ctx.cin_slice is not None:
+                raise NotImplementedError("Conv2dFn: input gradient of a channel-sliced input")
+            k = tuple(w.shape[2:])
+            if (k, s, p) == ((3, 3), 1, 1):
+                dx = ops.conv2d(dout, _derived(h).get("flip", [w], lambda: _wflip3(w)), None, stride=1, pad=1)
+            elif (k, s, p) == ((4, 4), 2, 1):
+                d4 = ops.conv2d(dout, _derived(h).get("T4", [w], lambda: _wT4(w)), None, stride=1, pad=1)
+                dx = ops.pixel_shuffle2(d4)
+            else:
+                raise NotImplementedError(f"Conv2dFn: input gradient for kernel {k} stride {s} pad {p}")
+        return dx, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# VSSBlock (vmamba.py:1319-1334) as one node
+# ------------------------------------------------------------------------------------------------------------------
+def _transpose_into(src, dst, dst_c0):
+    """dst[:, dst_c0 : dst_c0 + C] (B,*,H,W) = planes of src (B,C,W,H) transposed."""
+    B, C, Ws, Hs = src.shape
+    L = Ws * Hs
+    check(lib().bem_transpose_planes_f32(ctypes.c_void_p(src.data_ptr()), C * L, ctypes.c_void_p(dst.data_ptr() + 4 * dst_c0 * L),
+                                         dst.shape[1] * L, B, C, Ws, Hs, ops._stream()), "transpose_planes(into)")
+
+
+class VSSBlockFn(Function):
+    @staticmethod
+    def forward(ctx, x, blk, *params):
+        from .modules import _out_features
+        x = x.contiguous()
+        op, mlp = blk.op, blk.mlp
+        B, C, H, W = x.shape
+        Ci, R, L = op.d_inner, op.dt_rank, H * W
+        n1, n2, on = blk.norm, blk.norm2, op.out_norm
+        Wp, b = op.in_proj.gemm_weights(B)
+        t = ops.pw_gemm(x, Wp, Ci, ln=(n1.weight.detach(), n1.bias.detach()), ln_eps=n1.eps, bias=b)
+        cw, cb = op.conv2d.dw_weights(B)
+        xc = ops.dwconv3x3(t, cw, cb, mode=1)
+        wall, dtw, dtb, A, Ds = op._scan_params()
+        xd = ops.pw_gemm(xc, wall, 4 * (R + 2))
+        xd1 = ops.transpose_plane_slice(xd, 2 * (R + 2), 2 * (R + 2))
+        xcT = None
+        if ops.ss2d_scan_rm_supported(H, W, R):
+            y0, y1 = ops.ss2d_scan_rm(xc, xd.view(B, 4, R + 2, L)[:, :2], xd1.view(B, 2, R + 2, L), dtw, dtb, A, Ds)
+        else:
+            xcT = ops.transpose_planes(xc)
+            y0, y1T = ops.ss2d_scan(xc.view(B, Ci, L), xcT.view(B, Ci, L), xd.view(B, 4, R + 2, L)[:, :2], xd1.view(B, 2, R + 2, L), dtw, dtb, A, Ds)
+            y0, y1 = y0.view(B, Ci, H, W), ops.transpose_planes(y1T.view(B, Ci, W, H))
+        Wp, b = op.out_proj.gemm_weights(B)
+        x2 = ops.pw_gemm(y0, Wp, _out_features(op.out_proj), x2=y1, in_mode=1, ln=(on.weight.detach(), on.bias.detach()), ln_eps=on.eps, bias=b, res=x)
+        Wp, b = mlp.project_in.gemm_weights(B)
+        t2 = ops.pw_gemm(x2, Wp, _out_features(mlp.project_in), ln=(n2.weight.detach(), n2.bias.detach()), ln_eps=n2.eps, bias=b)
+        dww, dwb = mlp.dwconv.dw_weights(B)
+        g = ops.dwconv3x3(t2, dww, dwb, mode=2)
+        Wp, b = mlp.project_out.gemm_weights(B)
+        out = ops.pw_gemm(g, Wp, _out_features(mlp.project_out), bias=b, res=x2)
+        ctx.blk = blk
+        ctx.save_for_backward(x, t, xc, xd, xd1, y0, y1, x2, t2, g)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        blk = ctx.blk
+        x, t, xc, xd, xd1, y0, y1, x2, t2, g = ctx.saved_tensors
+        dout = dout.contiguous()
+        op, mlp = blk.op, blk.mlp
+        B, C, H, W = x.shape
+        Ci, R, L = op.d_inner, op.dt_rank, H * W
+        n1, n2, on = blk.norm, blk.norm2, op.out_norm
+        pi, dwc, po = mlp.project_in, mlp.dwconv, mlp.project_out
+        Hd = po.weight.shape[1]
+        # ---- gdMlp: out = x2 + W_o g + b_o, g = GELU(h1) h2, h = dw(t2) + b, t2 = W_i LN2(x2) + b_i
+        ops.pw_wgrad_(dout, g, grad_of(po.weight), dbias=None if po.bias is None else grad_of(po.bias))
+        dg = ops.pw_gemm(dout, _pack(po, "T", [po.weight], lambda: _w2d(po.weight).t()), Hd)
+        dh = ops.dwact_bwd(t2, dwc.weight.detach(), None if dwc.bias is None else dwc.bias.detach(), dg, grad_of(dwc.weight),
+                           None if dwc.bias is None else grad_of(dwc.bias), 2)
+        del dg
+        dt2 = ops.dwconv3x3(dh, _derived(dwc).get("flip", [dwc.weight], lambda: dwc.weight.detach().flip(2, 3).contiguous()), None, mode=0)
+        del dh
+        dn2 = ops.pw_gemm(dt2, _pack(pi, "T", [pi.weight], lambda: _w2d(pi.weight).t()), C)
+        dx2, nrm = ops.ln_bwd(x2, dn2, n2.weight.detach(), n2.bias.detach(), n2.eps, grad_of(n2.weight), grad_of(n2.bias), dres=dout)
+        del dn2
+        ops.pw_wgrad_(dt2, nrm, grad_of(pi.weight), dbias=None if pi.bias is None else grad_of(pi.bias))
+        del dt2, nrm
+        # ---- SS2D: x2 = x + W_out LN_on(y0 + y1)
+        opw = op.out_proj
+        dysn = ops.pw_gemm(dx2, _pack(opw, "T", [opw.weight], lambda: _w2d(opw.weight).t()), Ci)
+        dys, nys = ops.ln_bwd(y0, dysn, on.weight.detach(), on.bias.detach(), on.eps, grad_of(on.weight), grad_of(on.bias), x2=y1)
+        del dysn
+        ops.pw_wgrad_(dx2, nys, grad_of(opw.weight), dbias=None if opw.bias is None else grad_of(opw.bias))
+        del nys
+        wall, dtw, dtb, A, Ds = op._scan_params()
+        dysT = ops.transpose_planes(dys)
+        xcT = ops.transpose_planes(xc)
+        dx0, dx1T, dxd0, dxd1 = ops.ss2d_scan_bwd(
+            xc.view(B, Ci, L), xcT.view(B, Ci, L), xd.view(B, 4, R + 2, L)[:, :2], xd1.view(B, 2, R + 2, L), dys.view(B, Ci, L), dysT.view(B, Ci, L),
+            dtw, dtb, A, Ds, grad_of(op.A_logs), grad_of(op.Ds), grad_of(op.dt_projs_weight), grad_of(op.dt_projs_bias))
+        del dysT, xcT, dys
+        # x_dbl gradient back in the stacked row order of the forward GEMM: [dir 0 | dir 2 | dir 1 | dir 3], row-major pixels
+        dxd = torch.empty(B, 4 * (R + 2), H, W, device=x.device, dtype=x.dtype)
+        ops.copy_channels(dxd0.view(B, 2 * (R + 2), H, W), dxd, 0)
+        _transpose_into(dxd1.view(B, 2 * (R + 2), W, H), dxd, 2 * (R + 2))
+        ops.pw_wgrad_(dxd, xc, grad_of(op.x_proj_weight), blk_rows=R + 2, perm=(0, 2, 1, 3))
+        xw = op.x_proj_weight
+        wallT = _pack(op, "wallT", [xw], lambda: torch.cat([xw.detach()[0], xw.detach()[2], xw.detach()[1], xw.detach()[3]], 0).t())
+        dxc = ops.pw_gemm(dxd, wallT, Ci, res=dx0.view(B, Ci, H, W))
+        dxc = ops.add(dxc, ops.transpose_planes(dx1T.view(B, Ci, W, H)))
+        del dx0, dx1T, dxd, dxd0, dxd1
+        cv = op.conv2d
+        dpre = ops.dwact_bwd(t, cv.weight.detach(), None if cv.bias is None else cv.bias.detach(), dxc, grad_of(cv.weight),
+                             None if cv.bias is None else grad_of(cv.bias), 1)
+        dt = ops.dwconv3x3(dpre, _derived(cv).get("flip", [cv.weight], lambda: cv.weight.detach().flip(2, 3).contiguous()), None, mode=0)
+        del dpre, dxc
+        ipw = op.in_proj
+        dn = ops.pw_gemm(dt, _pack(ipw, "T", [ipw.weight], lambda: _w2d(ipw.weight).t()), C)
+        need_dx = ctx.needs_input_grad[0]
+        dx, nrm = ops.ln_bwd(x, dn, n1.weight.detach(), n1.bias.detach(), n1.eps, grad_of(n1.weight), grad_of(n1.bias), dres=dx2)
+        ops.pw_wgrad_(dt, nrm, grad_of(ipw.weight), dbias=None if ipw.bias is None else grad_of(ipw.bias))
+        return (dx if need_dx else None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+def vssblock_params(blk):
+    return [p for p in blk.parameters() if p.requires_grad]
+
+
+def vssblock(blk, x):
+    return VSSBlockFn.apply(x, blk, *vssblock_params(blk))

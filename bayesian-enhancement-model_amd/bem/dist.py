@@ -1,9 +1,18 @@
-"""Multi-GPU layer: one process per GPU, (image, sample) pairs sharded image-major across ranks, one
-exchange step -- an RCCL all-gather (torch.distributed backend "nccl" is RCCL on ROCm) of the finished
-candidates and their scores, so that every rank can run the per-image selection (eval.py:268-297) on
-all candidates.  No collective touches the data path before that: Stage-I / Stage-II are embarrassingly
-parallel over (image, sample) pairs and the weights are replicated."""
+"""Multi-GPU layer: one process per GPU, (image, sample) pairs sharded image-major across ranks, ONE exchange step -- an RCCL
+all-gather (torch.distributed backend "nccl" is RCCL on ROCm) over xGMI -- then the per-image selection of eval.py:268-297 on the
+gathered set.  No collective touches the data path before that: Stage-I / Stage-II are independent per (image, sample) pair and
+the weights are replicated (2.8 M + 2.7 M parameters).
+
+Two forms of the exchange (BASELINE north star asks for the first; SURVEY 5 / 8e prices both):
+  candidates : every rank gathers every candidate (B*N/W, 3, h, w) and its score, selects on the full set
+               (config 5: 369 MB per rank, ~17 ms on a ring, per-link bound);
+  scores     : ranks select locally (image-major sharding keeps an image's N candidates on one rank), gather the winners and
+               the score table only (N x less payload).
+Both return identical (best index, best image) for every image -- tests/test_dist_cpu.py.
+The reference has no collective on this path: nothing to mirror, only results to match."""
 from __future__ import annotations
+
+from typing import Callable, List, Optional
 
 import torch
 import torch.distributed as dist
@@ -17,22 +26,22 @@ def shard_images(n_images: int, rank: int, world: int):
     return start, start + per + (1 if rank < rem else 0)
 
 
+def _all_gather_rows(t: torch.Tensor, world: int) -> torch.Tensor:
+    """(n, ...) on every rank (equal n) -> (world * n, ...) rank-major.  nccl: one all_gather_into_tensor; gloo (CPU tests): list form."""
+    t = t.contiguous()
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
+    if dist.get_backend() == "gloo":
+        dist.all_gather(list(out.chunk(world)), t)
+    else:
+        dist.all_gather_into_tensor(out, t)
+    return out
+
+
 def gather_candidates(final: torch.Tensor, score: torch.Tensor, world: int):
-    """final (Bn,3,h,w), score (Bn) on every rank (equal shapes) -> (world*Bn,3,h,w), (world*Bn) on every
-    rank, rank-major.  Works with backend nccl (GPU tensors) and gloo (CPU tensors, used by the CPU tests)."""
+    """final (Bn,3,h,w), score (Bn) on every rank (equal shapes) -> (world*Bn,3,h,w), (world*Bn) on every rank, rank-major."""
     if world == 1:
         return final, score
-    out_f = torch.empty((world * final.shape[0],) + tuple(final.shape[1:]), device=final.device, dtype=final.dtype)
-    out_s = torch.empty(world * score.shape[0], device=score.device, dtype=score.dtype)
-    if dist.get_backend() == "gloo":
-        fl = list(out_f.chunk(world))
-        sl = list(out_s.chunk(world))
-        dist.all_gather(fl, final.contiguous())
-        dist.all_gather(sl, score.contiguous())
-    else:
-        dist.all_gather_into_tensor(out_f, final.contiguous())
-        dist.all_gather_into_tensor(out_s, score.contiguous())
-    return out_f, out_s
+    return _all_gather_rows(final, world), _all_gather_rows(score, world)
 
 
 def gather_ragged(final: torch.Tensor, score: torch.Tensor, counts, world: int):
@@ -49,12 +58,87 @@ def gather_ragged(final: torch.Tensor, score: torch.Tensor, counts, world: int):
     return f.index_select(0, keep), s.index_select(0, keep)
 
 
+def first_best(score_rows: List[List[float]], rule: str = "max") -> List[int]:
+    """Python ``list.index(max(...))`` / ``index(min(...))`` per image (eval.py:268-285): FIRST occurrence on ties."""
+    pick = max if rule == "max" else min
+    return [row.index(pick(row)) for row in score_rows]
+
+
 def select_best(score: torch.Tensor, samples_per_image: int):
-    """First maximum per image (list.index(max) semantics of eval.py:285)."""
-    s = score.view(-1, samples_per_image).cpu().tolist()
+    """eval.py:284-285 with psnr_weight = 1: index of the first maximum of psnr / max(psnr) per image."""
     best = []
-    for row in s:
+    for row in score.view(-1, samples_per_image).cpu().tolist():
         m = max(row)
+        if m == 0:               # no usable score (e.g. all-zero PSNR without targets): the reference's first candidate
+            best.append(0)
+            continue
         rel = [v / m for v in row]
         best.append(rel.index(max(rel)))
     return best
+
+
+def _select_device(final, score, N):
+    """Selection without leaving the device: the HIP kernel on GPU tensors, a torch restatement of the same first-maximum rule on
+    CPU tensors (gloo tests).  Returns (best (B) int64, best images (B,3,h,w))."""
+    B = final.shape[0] // N
+    if final.is_cuda:
+        from . import ops
+        best, _, img = ops.select_best(final.contiguous(), score.contiguous(), N)
+        return best.long(), img
+    s = score.view(B, N)
+    m = s.max(dim=1, keepdim=True).values
+    rel = torch.where(m != 0, s / torch.where(m != 0, m, torch.ones_like(m)), torch.zeros_like(s))
+    top = rel.max(dim=1, keepdim=True).values
+    best = (rel == top).float().argmax(dim=1)                      # first index of the maximum
+    img = final.view(B, N, *final.shape[1:])[torch.arange(B), best]
+    return best, img
+
+
+def exchange_and_select(final: torch.Tensor, score: torch.Tensor, samples_per_image: int, world: int, mode: str = "candidates",
+                        counts: Optional[List[int]] = None):
+    """The exchange step + selection.  final (Bn_local,3,h,w), score (Bn_local), rows = image*N + sample (image-major shard).
+    Returns (best images (B_total,3,h,w), best index (B_total)) on every rank, images in global order.
+    counts: images per rank when the shards are ragged (None = equal)."""
+    N = samples_per_image
+    if world == 1:
+        best, img = _select_device(final, score, N)
+        return img, best
+    if mode == "candidates":
+        if counts is None:
+            f, s = gather_candidates(final, score, world)
+        else:
+            f, s = gather_ragged(final, score, [c * N for c in counts], world)
+        best, img = _select_device(f, s, N)
+        return img, best
+    if mode != "scores":
+        raise ValueError(f"exchange_and_select: unknown mode {mode}")
+    best, img = _select_device(final, score, N)
+    if counts is None:
+        return _all_gather_rows(img, world), _all_gather_rows(best, world)
+    m = max(counts)
+    pad = m - img.shape[0]
+    if pad:
+        img = torch.cat([img, img.new_zeros((pad,) + tuple(img.shape[1:]))])
+        best = torch.cat([best, best.new_zeros(pad)])
+    gi, gb = _all_gather_rows(img, world), _all_gather_rows(best, world)
+    keep = torch.cat([torch.arange(r * m, r * m + c) for r, c in enumerate(counts)]).to(gi.device)
+    return gi.index_select(0, keep), gb.index_select(0, keep)
+
+
+def enhance_sharded(enhance: Callable, imgs: torch.Tensor, targets: Optional[torch.Tensor], num_samples: int, rank: int, world: int,
+                    mode: str = "candidates", **kw):
+    """The whole multi-GPU eval step for a GLOBAL batch present on every rank: image-major shard -> local ``enhance`` (any callable
+    with BEMPipeline.enhance's contract: returns dict(final (b*N,3,h,w), psnr (b*N), N)) -> exchange -> selection.
+    Returns (best images (B,3,h,w), best index (B)) -- equal on every rank and equal to the unsharded result."""
+    B = imgs.shape[0]
+    lo, hi = shard_images(B, rank, world)
+    counts = [shard_images(B, r, world)[1] - shard_images(B, r, world)[0] for r in range(world)]
+    if hi > lo:
+        r = enhance(imgs[lo:hi], None if targets is None else targets[lo:hi], num_samples, **kw)
+        final, score, N = r["final"], r["psnr"], r["N"]
+    else:                                             # more ranks than images: an empty shard still joins the collective
+        N = kw.get("N_hint", num_samples)
+        final = imgs.new_zeros((0, 3) + tuple(imgs.shape[2:]))
+        score = imgs.new_zeros((0,))
+    ragged = len(set(counts)) > 1
+    return exchange_and_select(final, score, N, world, mode, counts if ragged else None)

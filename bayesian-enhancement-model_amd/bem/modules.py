@@ -15,6 +15,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn as nn
 
+from . import autograd as ag
 from . import ops
 from .native import BemNativeError
 
@@ -29,7 +30,7 @@ class _Cache:
         self._d = {}
 
     def get(self, key, srcs, fn):
-        sig = tuple((t.data_ptr(), t._version, t.device) for t in srcs)
+        sig = (ops.WEIGHT_EPOCH[0],) + tuple((t.data_ptr(), t._version, t.device) for t in srcs)
         hit = self._d.get(key)
         if hit is not None and hit[0] == sig:
             return hit[1]
@@ -44,6 +45,12 @@ class _Cache:
 GATE_PROJ = __import__("os").environ.get("BEM_GATE_PROJ", "0") != "0"
 SCAN_RM = os.environ.get("BEM_SCAN_RM", "1") != "0"          # row-major SS2D scan (no transposes of xc / y1) where the plane size allows
 FUSE_GDMLP = os.environ.get("BEM_FUSE_GDMLP", "0") != "0"    # 0: unfused three-kernel gdMlp (kept for A/B checks)
+
+
+def grad_mode(m: nn.Module) -> bool:
+    """True when a forward has to record the training graph: module in train() mode with autograd enabled (the reference's
+    training step, image_enhancer_model.py:165-216).  Everything else runs the inference kernels only."""
+    return m.training and torch.is_grad_enabled()
 
 
 def _need_cuda(x):
@@ -62,16 +69,20 @@ class SampleCtx:
 
     _epoch = 0      # process-wide forward counter: successive forwards never reuse a Philox stream
 
-    def __init__(self, nsets: int, eps: Optional[Dict[str, torch.Tensor]] = None, seed: int = 0):
-        self.nsets, self.eps, self.seed = nsets, eps, seed
+    def __init__(self, nsets: int, eps: Optional[Dict[str, torch.Tensor]] = None, seed: int = 0, rank: int = 0):
+        self.nsets, self.eps, self.seed, self.rank = nsets, eps, seed, rank
         self.counter = 0
         SampleCtx._epoch += 1
         self.epoch = SampleCtx._epoch
 
     def next_stream(self):
-        """A fresh Philox stream id per sampled tensor: (forward epoch, tensor counter)."""
+        """A fresh Philox stream id per sampled tensor: [rank : 16 bits | forward epoch : 24 bits | tensor counter : 20 bits].
+        Ranks of a multi-GPU run that share ``seed`` therefore draw different weight sets; bit 62 is reserved for the
+        condition-noise draws (BEMPipeline.candidates)."""
         self.counter += 1
-        return (self.epoch << 20) + self.counter
+        if self.counter >= (1 << 20) or self.epoch >= (1 << 24):
+            raise RuntimeError("SampleCtx: Philox stream id space exhausted (2^20 tensors per forward, 2^24 forwards per process)")
+        return (self.rank << 44) | (self.epoch << 20) | self.counter
 
 
 _SAMPLE_CTX: List[Optional[SampleCtx]] = [None]
@@ -122,8 +133,18 @@ class Linear2d(nn.Linear):
 
     def forward(self, x, **kw):
         _need_cuda(x)
+        if grad_mode(self):
+            return _pw_train(self, x, kw)
         Wp, b = self.gemm_weights(x.shape[0])
         return ops.pw_gemm(x, Wp, self.out_features, bias=b, **kw)
+
+
+def _pw_train(m, x, kw):
+    """Training-mode forward of a plain 1x1 layer (optionally over the concatenation of two inputs)."""
+    extra = set(kw) - {"x2", "in_mode"}
+    if extra or (("x2" in kw) != (kw.get("in_mode", 0) == 2)):
+        raise BemNativeError(f"1x1 layer: the training path covers plain and concat-input forms only (got {sorted(kw)})")
+    return ag.PwFn.apply(x, kw.get("x2"), m.weight, m.bias, m)
 
 
 class PwConv2d(nn.Conv2d):
@@ -141,6 +162,8 @@ class PwConv2d(nn.Conv2d):
 
     def forward(self, x, **kw):
         _need_cuda(x)
+        if grad_mode(self):
+            return _pw_train(self, x, kw)
         Wp, b = self.gemm_weights(x.shape[0])
         return ops.pw_gemm(x, Wp, self.out_channels, bias=b, **kw)
 
@@ -161,6 +184,10 @@ class Conv2dK(nn.Conv2d):
 
     def forward(self, x, relu=False, res1=None, res2=None, cin_slice=None):
         _need_cuda(x)
+        if grad_mode(self) and self.weight.requires_grad:
+            if relu or res1 is not None or res2 is not None:
+                raise BemNativeError("Conv2dK: the training path covers the plain convolution (+ bias) only")
+            return ag.Conv2dFn.apply(x, self.weight, self.bias, self, cin_slice)
         return ops.conv2d(x, self.weight.detach(), None if self.bias is None else self.bias.detach(),
                           stride=self.stride[0], pad=self.padding[0], relu=relu, res1=res1, res2=res2, cin_slice=cin_slice)
 
@@ -174,6 +201,11 @@ class ConvT2x2(nn.ConvTranspose2d):
 
     def forward(self, x):
         _need_cuda(x)
+        if grad_mode(self):
+            return ag.ConvT2x2Fn.apply(x, self.weight, self.bias, self)
+        return self._forward_nograd(x)
+
+    def _forward_nograd(self, x):
         co = self.out_channels
 
         def prep():
@@ -453,6 +485,8 @@ class VSSBlock(nn.Module):
 
     def forward(self, x):
         _need_cuda(x)
+        if grad_mode(self):
+            return ag.vssblock(self, x)
         x = x.contiguous()
         x = self.op.forward_fused(x, self.norm)
         return self.mlp.forward_fused(x, self.norm2)

@@ -42,6 +42,18 @@ class GdmlpArgs(ctypes.Structure):
     ]
 
 
+class WgradArgs(ctypes.Structure):
+    """Mirror of ``bem_wgrad_args`` (include/bem_hip.h)."""
+    _fields_ = [
+        ("dy", c_void_p), ("dy_bstride", c_int64), ("M", c_int),
+        ("x1", c_void_p), ("x1_bstride", c_int64), ("C1", c_int),
+        ("x2", c_void_p), ("x2_bstride", c_int64), ("C2", c_int),
+        ("dw", c_void_p), ("ldw", c_int64), ("blk_rows", c_int), ("perm", c_int * 4),
+        ("dbias", c_void_p),
+        ("B", c_int), ("L", c_int),
+    ]
+
+
 P, I, I64, U64, F = c_void_p, c_int, c_int64, c_uint64, c_float
 
 # name -> argtypes (return type int unless listed in _RESTYPE); this table is what the
@@ -92,6 +104,19 @@ SIGNATURES = {
     "bem_cond_postproc_f32": [P, P, P, P, I, I, I, I, F, P],
     "bem_plane_mean_f32": [P, P, I, I, I, I, I, P],
     "bem_candidate_finalize_f32": [P, P, P, P, P, I, I, I, I, I, I, I, P],
+    "bem_l1_loss_f32": [P, P, P, P, P, I64, F, P, P],
+    "bem_iwt_hamilton_bwd_f32": [P, P, P, P, P, I, I, I, P],
+    "bem_pixel_unshuffle2_f32": [P, P, I, I, I, I, P],
+    "bem_channel_sum_f32": [P, P, I, I, I64, P],
+    "bem_add_f32": [P, P, P, I64, F, P],
+    "bem_ln_bwd_f32": [P, P, P, P, P, F, P, P, P, P, P, I, I, I64, P],
+    "bem_ln_fwd_f32": [P, P, P, P, F, P, I, I, I64, P],
+    "bem_dwact_bwd_f32": [P, P, P, P, P, P, P, I, I, I, I, I, P],
+    "bem_pw_wgrad_f32": [ctypes.POINTER(WgradArgs), P],
+    "bem_conv_wgrad_f32": [P, P, I64, P, P, I, I, I, I, I, I, I, I, I, P],
+    "bem_ss2d_scan_bwd_f32": [P] * 18 + [I, I, I, I, I64, I64, P],
+    "bem_grad_sumsq_f32": [P, I64, P, P],
+    "bem_adamw_step_f32": [P, P, P, P, I64, F, F, F, F, F, I, F, P, P, P],
     "bem_last_error": [],
     "bem_abi_version": [],
 }
@@ -103,7 +128,7 @@ _lib = None
 def build(verbose: bool = False) -> str:
     """Compile csrc/*.hip for gfx950 into lib/libbem_hip.so (hipcc cross-compiles without a GPU)."""
     import subprocess
-    r = subprocess.run(["make", "-C", CSRC], capture_output=True, text=True)
+    r = subprocess.run(["make", "-j8", "-C", CSRC], capture_output=True, text=True)
     if r.returncode != 0:
         raise BemNativeError(f"building libbem_hip.so failed:\n{r.stdout}\n{r.stderr}")
     if verbose:

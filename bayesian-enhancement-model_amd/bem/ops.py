@@ -114,7 +114,7 @@ def ss2d_scan(x0, x1, xd0, xd1, dtw, dtb, A, Ds):
     for n, t in (("xd0", xd0), ("xd1", xd1)):
         if not t.is_cuda or t.dtype != torch.float32:
             raise native.BemNativeError(f"{n} must be a float32 CUDA/HIP tensor")
-        if t.stride()[1:] != ((R + 2) * L, L, 1) or (B > 1 and (t.stride(0) < 2 * (R + 2) * L or t.stride(0) % 4)):
+        if t.stride()[1:] != ((R + 2) * L, L, 1) or (B > 1 and (t.stride(0) < 2 * (R + 2) * L or (L % 4 == 0 and t.stride(0) % 4))):
             raise ValueError(f"{n}: only the batch stride may differ from a contiguous (B,2,R+2,L) tensor")
         bs.append(t.stride(0) if B > 1 else 0)
     y0 = torch.empty_like(x0)
@@ -143,7 +143,7 @@ def ss2d_scan_rm(x, xd0, xd1, dtw, dtb, A, Ds):
     for n, t in (("xd0", xd0), ("xd1", xd1)):
         if not t.is_cuda or t.dtype != torch.float32:
             raise native.BemNativeError(f"{n} must be a float32 CUDA/HIP tensor")
-        if t.stride()[1:] != ((R + 2) * L, L, 1) or (B > 1 and (t.stride(0) < 2 * (R + 2) * L or t.stride(0) % 4)):
+        if t.stride()[1:] != ((R + 2) * L, L, 1) or (B > 1 and (t.stride(0) < 2 * (R + 2) * L or (L % 4 == 0 and t.stride(0) % 4))):
             raise ValueError(f"{n}: only the batch stride may differ from a contiguous (B,2,R+2,L) tensor")
         bs.append(t.stride(0) if B > 1 else 0)
     y0, y1 = torch.empty_like(x), torch.empty_like(x)
@@ -170,6 +170,13 @@ def transpose_plane_slice(x, c0, C):
 # the matrix-pipe cost).  pack_pw_weight picks the format, pw_gemm recognises it from the packed size (the two sizes
 # never coincide: 32 ceil(K/2) vs 768 ceil(K/16) floats per M-tile).  BEM_PW_X6=0 selects the f32 kernels everywhere.
 USE_X6 = __import__("os").environ.get("BEM_PW_X6", "1") != "0"
+# Bumped whenever parameters are rewritten behind torch's back (the fused optimizer step, bem.train.BemAdamW): every cache of
+# derived weights (packed / transposed / flipped copies) is keyed on it as well as on the tensors' data_ptr / _version.
+WEIGHT_EPOCH = [0]
+
+
+def bump_weight_epoch():
+    WEIGHT_EPOCH[0] += 1
 
 
 def packed_elems(M: int, K: int, x6: bool = False) -> int:
@@ -376,7 +383,7 @@ USE_CONV_MFMA = __import__("os").environ.get("BEM_CONV_MFMA", "1") != "0"
 
 
 def _packed_conv_weight(w):
-    key = (w.data_ptr(), w._version, tuple(w.shape))
+    key = (w.data_ptr(), w._version, tuple(w.shape), WEIGHT_EPOCH[0])
     hit = _CONV_PACK.get(key)
     if hit is None:
         if len(_CONV_PACK) > 256:
@@ -394,7 +401,7 @@ USE_CONV4_X6 = __import__("os").environ.get("BEM_CONV4_X6", "0") != "0"
 
 
 def _packed_conv_weight_x6(w):
-    key = (w.data_ptr(), w._version, tuple(w.shape))
+    key = (w.data_ptr(), w._version, tuple(w.shape), WEIGHT_EPOCH[0])
     hit = _CONV_PACK_X6.get(key)
     if hit is None:
         if len(_CONV_PACK_X6) > 256:
@@ -698,6 +705,207 @@ def select_best(final, psnr, samples_per_image):
     return best, bp, img
 
 
+# --------------------------------------------------------------------------- training step ----
+# Backward kernels + optimizer.  Parameter-gradient outputs (dw, dbias, dgamma, ...) are
+# ACCUMULATED INTO: they are views of the parameters' .grad buffers.
+def l1_loss(pred, gt, weight=1.0):
+    """loss (1,) = weight * mean |pred - gt|."""
+    _chk(pred, "pred"); _chk(gt, "gt")
+    if pred.shape != gt.shape:
+        raise ValueError("l1_loss: shapes differ")
+    loss = torch.empty(1, device=pred.device, dtype=torch.float32)
+    ws = torch.empty(1, device=pred.device, dtype=torch.float64)
+    check(lib().bem_l1_loss_f32(_p(pred), _p(gt), _p(None), _p(loss), _p(ws), pred.numel(), float(weight), _p(None), _stream()), "l1_loss")
+    return loss
+
+
+def l1_loss_bwd(pred, gt, weight=1.0, gmul=None):
+    """dpred = gmul * weight * sign(pred - gt) / numel  (gmul: device scalar dL/dloss, None = 1)."""
+    _chk(pred, "pred"); _chk(gt, "gt"); _chk(gmul, "gmul", optional=True)
+    dp = torch.empty_like(pred)
+    ws = torch.empty(1, device=pred.device, dtype=torch.float64)
+    check(lib().bem_l1_loss_f32(_p(pred), _p(gt), _p(dp), _p(None), _p(ws), pred.numel(), float(weight), _p(gmul), _stream()), "l1_loss_bwd")
+    return dp
+
+
+def iwt_hamilton_bwd(q1w, q2w, dout):
+    _chk(q1w, "q1w"); _chk(q2w, "q2w"); _chk(dout, "dout")
+    B, C, h, w = q1w.shape
+    if C != 16 or q2w.shape != q1w.shape or tuple(dout.shape) != (B, 3, 2 * h, 2 * w):
+        raise ValueError("iwt_hamilton_bwd: shapes")
+    d1, d2 = torch.empty_like(q1w), torch.empty_like(q2w)
+    check(lib().bem_iwt_hamilton_bwd_f32(_p(q1w), _p(q2w), _p(dout), _p(d1), _p(d2), B, h, w, _stream()), "iwt_hamilton_bwd")
+    return d1, d2
+
+
+def pixel_unshuffle2(x):
+    """nn.PixelUnshuffle(2): (B,C,2H,2W) -> (B,4C,H,W)."""
+    _chk(x, "x")
+    B, C, H2, W2 = x.shape
+    if H2 % 2 or W2 % 2:
+        raise ValueError("pixel_unshuffle2: even H, W required")
+    out = torch.empty(B, 4 * C, H2 // 2, W2 // 2, device=x.device, dtype=x.dtype)
+    check(lib().bem_pixel_unshuffle2_f32(_p(x), _p(out), B, C, H2 // 2, W2 // 2, _stream()), "pixel_unshuffle2")
+    return out
+
+
+def channel_sum_(x, out):
+    """out[c] += sum_{b,p} x[b][c][p]."""
+    _chk(x, "x"); _chk(out, "out")
+    B, C = x.shape[0], x.shape[1]
+    if out.numel() != C:
+        raise ValueError("channel_sum: out size")
+    check(lib().bem_channel_sum_f32(_p(x), _p(out), B, C, x[0, 0].numel(), _stream()), "channel_sum")
+    return out
+
+
+def add(a, b, alpha=1.0):
+    """a + alpha * b."""
+    _chk(a, "a"); _chk(b, "b")
+    if a.shape != b.shape:
+        raise ValueError("add: shapes differ")
+    out = torch.empty_like(a)
+    check(lib().bem_add_f32(_p(a), _p(b), _p(out), a.numel(), float(alpha), _stream()), "add")
+    return out
+
+
+def ln_bwd(x1, dn, gamma, beta, eps, dgamma, dbeta, x2=None, dres=None, want_n=True):
+    """LayerNorm2d backward over channels of x = x1 (+ x2): returns (dx, n = LN(x) | None); dgamma / dbeta accumulated."""
+    for n, t in (("x1", x1), ("dn", dn), ("gamma", gamma), ("beta", beta), ("dgamma", dgamma), ("dbeta", dbeta)):
+        _chk(t, n)
+    _chk(x2, "x2", optional=True); _chk(dres, "dres", optional=True)
+    B, C = x1.shape[0], x1.shape[1]
+    if dn.shape != x1.shape or (x2 is not None and x2.shape != x1.shape) or (dres is not None and dres.shape != x1.shape):
+        raise ValueError("ln_bwd: activation shapes")
+    if gamma.numel() != C or beta.numel() != C or dgamma.numel() != C or dbeta.numel() != C:
+        raise ValueError("ln_bwd: parameter sizes")
+    dx = torch.empty_like(x1)
+    nn_ = torch.empty_like(x1) if want_n else None
+    check(lib().bem_ln_bwd_f32(_p(x1), _p(x2), _p(dn), _p(gamma), _p(beta), float(eps), _p(dres), _p(dx), _p(nn_), _p(dgamma), _p(dbeta),
+                               B, C, x1[0, 0].numel(), _stream()), "ln_bwd")
+    return dx, nn_
+
+
+def ln_fwd(x1, gamma, beta, eps, x2=None):
+    _chk(x1, "x1"); _chk(gamma, "gamma"); _chk(beta, "beta"); _chk(x2, "x2", optional=True)
+    B, C = x1.shape[0], x1.shape[1]
+    if gamma.numel() != C or beta.numel() != C or (x2 is not None and x2.shape != x1.shape):
+        raise ValueError("ln_fwd: shapes")
+    out = torch.empty_like(x1)
+    check(lib().bem_ln_fwd_f32(_p(x1), _p(x2), _p(gamma), _p(beta), float(eps), _p(out), B, C, x1[0, 0].numel(), _stream()), "ln_fwd")
+    return out
+
+
+def dwact_bwd(t, w, bias, dout, dw, dbias, mode):
+    """Backward of dwconv3x3(mode) through the activation: returns dpre (like t); dw (Cw,1,3,3) / dbias accumulated."""
+    _chk(t, "t"); _chk(w, "w"); _chk(bias, "bias", optional=True); _chk(dout, "dout"); _chk(dw, "dw"); _chk(dbias, "dbias", optional=True)
+    B, Cw, H, W = t.shape
+    Cout = Cw // 2 if mode == 2 else Cw
+    if tuple(dout.shape) != (B, Cout, H, W) or w.numel() != Cw * 9 or dw.numel() != Cw * 9 or (bias is None) != (dbias is None):
+        raise ValueError("dwact_bwd: shapes")
+    if bias is not None and (bias.numel() != Cw or dbias.numel() != Cw):
+        raise ValueError("dwact_bwd: bias shapes")
+    dpre = torch.empty_like(t)
+    check(lib().bem_dwact_bwd_f32(_p(t), _p(w), _p(bias), _p(dout), _p(dpre), _p(dw), _p(dbias), B, Cout, H, W, mode, _stream()), "dwact_bwd")
+    return dpre
+
+
+def pw_wgrad_(dy, x1, dw, x2=None, dbias=None, blk_rows=0, perm=(0, 1, 2, 3), dy_bstride=0, M=None):
+    """dw (M, C1 + C2) += dy . cat(x1, x2)^T over batch and pixels; dbias (M) += row sums of dy.
+    dy may be a channel slice of a wider tensor (pass M and dy_bstride)."""
+    _chk(x1, "x1"); _chk(x2, "x2", optional=True); _chk(dw, "dw"); _chk(dbias, "dbias", optional=True)
+    if not dy.is_cuda or dy.dtype != torch.float32:
+        raise native.BemNativeError("pw_wgrad: dy must be a float32 CUDA/HIP tensor")
+    B, C1 = x1.shape[0], x1.shape[1]
+    L = x1[0, 0].numel()
+    C2 = 0 if x2 is None else x2.shape[1]
+    if M is None:
+        _chk(dy, "dy")
+        M = dy.shape[1]
+    if dy.shape[0] != B or (x2 is not None and (x2.shape[0] != B or x2[0, 0].numel() != L)):
+        raise ValueError("pw_wgrad: batch / pixel counts")
+    if dw.numel() != M * (C1 + C2) or (dbias is not None and dbias.numel() != M):
+        raise ValueError(f"pw_wgrad: dw has {dw.numel()} elements, expected {M} x {C1 + C2}")
+    a = native.WgradArgs()
+    a.dy, a.dy_bstride, a.M = dy.data_ptr(), dy_bstride, M
+    a.x1, a.x1_bstride, a.C1 = x1.data_ptr(), 0, C1
+    a.x2, a.x2_bstride, a.C2 = (x2.data_ptr() if x2 is not None else 0), 0, C2
+    a.dw, a.ldw, a.blk_rows = dw.data_ptr(), C1 + C2, blk_rows
+    for i in range(4):
+        a.perm[i] = perm[i]
+    a.dbias = dbias.data_ptr() if dbias is not None else 0
+    a.B, a.L = B, L
+    check(lib().bem_pw_wgrad_f32(ctypes.byref(a), _stream()), "pw_wgrad")
+    return dw
+
+
+def conv_wgrad_(dy, x, dw, dbias=None, stride=1, pad=1, cin_slice=None):
+    """dw (Cout,Cin,KH,KW) += weight gradient of conv2d(x, w, stride, pad); dbias (Cout) += sum dy."""
+    _chk(dy, "dy"); _chk(x, "x"); _chk(dw, "dw"); _chk(dbias, "dbias", optional=True)
+    B, Ct, H, W = x.shape
+    Cout, Cin, KH, KW = dw.shape
+    c0 = 0
+    if cin_slice is not None:
+        c0, cs = cin_slice
+        if cs != Cin or c0 + Cin > Ct:
+            raise ValueError("conv_wgrad: channel slice")
+    elif Ct != Cin:
+        raise ValueError("conv_wgrad: channels")
+    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    if tuple(dy.shape) != (B, Cout, Ho, Wo) or (dbias is not None and dbias.numel() != Cout):
+        raise ValueError("conv_wgrad: dy / dbias shapes")
+    check(lib().bem_conv_wgrad_f32(_p(dy), ctypes.c_void_p(x.data_ptr() + 4 * c0 * H * W), Ct * H * W, _p(dw), _p(dbias), B, Cin, H, W, Cout,
+                                   KH, KW, stride, pad, _stream()), "conv_wgrad")
+    return dw
+
+
+def ss2d_scan_bwd(x0, x1, xd0, xd1, dy0, dy1, dtw, dtb, A, Ds, dAlog, dDs, ddtw, ddtb):
+    """Backward of ss2d_scan: returns (dx0, dx1, dxd0, dxd1); parameter gradients accumulated into dAlog (4C), dDs (4C),
+    ddtw (4,C,R), ddtb (4,C)."""
+    for n, t in (("x0", x0), ("x1", x1), ("dy0", dy0), ("dy1", dy1), ("dtw", dtw), ("dtb", dtb), ("A", A), ("Ds", Ds), ("dAlog", dAlog),
+                 ("dDs", dDs), ("ddtw", ddtw), ("ddtb", ddtb)):
+        _chk(t, n)
+    B, C, L = x0.shape
+    R = dtw.shape[2]
+    if x1.shape != x0.shape or dy0.shape != x0.shape or dy1.shape != x0.shape or xd0.shape != (B, 2, R + 2, L) or xd1.shape != xd0.shape:
+        raise ValueError("ss2d_scan_bwd: activation shapes")
+    if dtw.shape != (4, C, R) or dtb.shape != (4, C) or A.numel() != 4 * C or Ds.numel() != 4 * C or dAlog.numel() != 4 * C or dDs.numel() != 4 * C \
+            or ddtw.numel() != 4 * C * R or ddtb.numel() != 4 * C:
+        raise ValueError("ss2d_scan_bwd: parameter shapes")
+    bs = []
+    for n, t in (("xd0", xd0), ("xd1", xd1)):
+        if not t.is_cuda or t.dtype != torch.float32:
+            raise native.BemNativeError(f"{n} must be a float32 CUDA/HIP tensor")
+        if t.stride()[1:] != ((R + 2) * L, L, 1) or (B > 1 and (t.stride(0) < 2 * (R + 2) * L or (L % 4 == 0 and t.stride(0) % 4))):
+            raise ValueError(f"{n}: only the batch stride may differ from a contiguous (B,2,R+2,L) tensor")
+        bs.append(t.stride(0) if B > 1 else 0)
+    dx0, dx1 = torch.empty_like(x0), torch.empty_like(x0)
+    dxd0 = torch.empty(B, 2, R + 2, L, device=x0.device, dtype=x0.dtype)
+    dxd1 = torch.empty(B, 2, R + 2, L, device=x0.device, dtype=x0.dtype)
+    check(lib().bem_ss2d_scan_bwd_f32(_p(x0), _p(x1), _p(xd0), _p(xd1), _p(dy0), _p(dy1), _p(dtw), _p(dtb), _p(A), _p(Ds), _p(dx0), _p(dx1),
+                                      _p(dxd0), _p(dxd1), _p(dAlog), _p(dDs), _p(ddtw), _p(ddtb), B, C, L, R, bs[0], bs[1], _stream()),
+          "ss2d_scan_bwd")
+    return dx0, dx1, dxd0, dxd1
+
+
+def grad_sumsq(g, acc):
+    """acc (1,) f64 = sum g^2 over the flat gradient buffer."""
+    _chk(g, "g"); _chk(acc, "acc", dtype=torch.float64)
+    check(lib().bem_grad_sumsq_f32(_p(g), g.numel(), _p(acc), _stream()), "grad_sumsq")
+    return acc
+
+
+def adamw_step_(p, g, m, v, lr, betas, eps, weight_decay, step, max_norm=0.0, sumsq=None, norm_out=None):
+    for n, t in (("p", p), ("g", g), ("m", m), ("v", v)):
+        _chk(t, n)
+    _chk(sumsq, "sumsq", dtype=torch.float64, optional=True); _chk(norm_out, "norm_out", optional=True)
+    n = p.numel()
+    if g.numel() != n or m.numel() != n or v.numel() != n:
+        raise ValueError("adamw_step: buffer sizes differ")
+    check(lib().bem_adamw_step_f32(_p(p), _p(g), _p(m), _p(v), n, float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
+                                   int(step), float(max_norm), _p(sumsq), _p(norm_out), _stream()), "adamw_step")
+
+
 # --------------------------------------------------------------------------- launch timing ----
 # bench.py asks for ONE op's launches to be bracketed by HIP events on the launch stream (torch's
 # current stream is the stream every wrapper launches on), together with that launch's algorithmic
@@ -721,6 +929,12 @@ _KEYS = {
     "dwconv3x3": ("dwconv3x3", "hbm", "dwconv3x3_kernel", None),
     "ss2d_scan": ("ss2d_scan", "hbm", "ss2d_scan_kernel", None),
     "transpose_planes": ("transpose_planes", "hbm", "transpose_planes_kernel", None),
+    # training step (bench.py --config train)
+    "pw_wgrad": ("pw_wgrad_", "hbm", "wgrad_kernel<*> (1x1 weight gradients)", None),
+    "conv_wgrad": ("conv_wgrad_", "mfma", "wgrad_kernel<*> (dense conv weight gradients)", None),
+    "ss2d_scan_bwd": ("ss2d_scan_bwd", "hbm", "ss2d_scan_bwd_kernel", None),
+    "dwact_bwd": ("dwact_bwd", "hbm", "dwact_bwd_kernel", None),
+    "ln_bwd": ("ln_bwd", "hbm", "ln_bwd_kernel", None),
 }
 
 
@@ -821,6 +1035,46 @@ def _wrap_profiled():
         return out
 
     pw_gemm, conv2d, dwconv3x3, ss2d_scan, transpose_planes = pw_gemm_p, conv2d_p, dwconv3x3_p, ss2d_scan_p, transpose_planes_p
+
+    # backward ops: (algorithmic bytes, flops) of one launch from the call's arguments
+    def numel(t):
+        return 0 if t is None else t.numel()
+
+    def wrap(name, cost):
+        inner = globals()[name]
+
+        def wrapped(*a, **kw):
+            if _PROF is None or _PROF["kernel"] != name:
+                return inner(*a, **kw)
+            nb, nf = cost(*a, **kw)
+            s = _timed(name, nb, nf)
+            out = inner(*a, **kw)
+            _timed_end(s)
+            return out
+        wrapped.__doc__ = inner.__doc__
+        globals()[name] = wrapped
+
+    def c_pw_wgrad(dy, x1, dw, x2=None, dbias=None, blk_rows=0, perm=None, dy_bstride=0, M=None):
+        B, L = x1.shape[0], x1[0, 0].numel()
+        M = dy.shape[1] if M is None else M
+        K = x1.shape[1] + (0 if x2 is None else x2.shape[1])
+        return 4.0 * B * L * (M + K) + 4.0 * M * K, 2.0 * M * K * B * L
+
+    def c_conv_wgrad(dy, x, dw, dbias=None, stride=1, pad=1, cin_slice=None):
+        Cout, Cin, KH, KW = dw.shape
+        return 4.0 * (dy.numel() + x.shape[0] * Cin * x.shape[2] * x.shape[3]) + 4.0 * dw.numel(), 2.0 * dy.numel() * Cin * KH * KW
+
+    def c_scan_bwd(x0, x1, xd0, xd1, dy0, dy1, *a, **kw):
+        return 4.0 * (6 * x0.numel() + 4 * xd0.numel()), 0.0
+
+    def c_dwact(t, w, bias, dout, dw, dbias, mode):
+        return 4.0 * (2 * t.numel() + dout.numel()), 40.0 * t.numel()
+
+    def c_ln(x1, dn, gamma, beta, eps, dgamma, dbeta, x2=None, dres=None, want_n=True):
+        return 4.0 * x1.numel() * (3 + (x2 is not None) + (dres is not None) + bool(want_n)), 0.0
+
+    for nm, fn in (("pw_wgrad_", c_pw_wgrad), ("conv_wgrad_", c_conv_wgrad), ("ss2d_scan_bwd", c_scan_bwd), ("dwact_bwd", c_dwact), ("ln_bwd", c_ln)):
+        wrap(nm, fn)
 
 
 _wrap_profiled()

@@ -27,7 +27,7 @@ class BEMPipeline:
     @torch.no_grad()
     def candidates(self, imgs, targets, num_samples: int, gt_mean: bool, deterministic: bool = False,
                    eps: Optional[Dict[str, torch.Tensor]] = None, noise: Optional[torch.Tensor] = None,
-                   img_down: Optional[torch.Tensor] = None, seed: int = 0):
+                   img_down: Optional[torch.Tensor] = None, seed: int = 0, rank: int = 0):
         """imgs (B,3,h,w) in [0,1] on the GPU, targets (B,3,h,w) or None.
         Returns dict(conds (B*N,3,hd,wd), raw (B*N,3,Hp,Wp), final (B*N,3,h,w), psnr (B*N)); row = image*N + sample."""
         from basicsr.bayesian import set_prediction_type
@@ -42,11 +42,12 @@ class BEMPipeline:
         hd, wd = img_down.shape[-2:]
         x1 = img_down[:, None].expand(B, N, 3, hd, wd).reshape(B * N, 3, hd, wd)  # (B*N,3,hd,wd): row = image*N + sample
         set_prediction_type(self.net1, deterministic)
-        with sampling(None if deterministic else SampleCtx(B * N, eps, seed)):
+        with sampling(None if deterministic else SampleCtx(B * N, eps, seed, rank=rank)) as ctx:
             pred = self.net1(x1)[-1]
         tmean = ops.plane_mean(targets.contiguous()) if (gt_mean and targets is not None) else None
         if noise is None and self.noise_level:
-            noise = ops.randn(tuple(pred.shape), pred.device, seed, (1 << 40) + SampleCtx._epoch)   # torch.randn_like of eval.py:209
+            # torch.randn_like of eval.py:209: its own key space (bit 62 of the stream id), per rank and per forward
+            noise = ops.randn(tuple(pred.shape), pred.device, seed, (1 << 62) | (rank << 44) | SampleCtx._epoch)
         conds = ops.cond_postproc(pred, tmean, noise if self.noise_level else None, N, self.noise_level)
         cond_up = ops.bilinear_up(conds, self.scale)                             # (B*N,3,Hp,Wp)
         d_img = self.net2.decompose(pad, 0)                                      # once per image
@@ -60,6 +61,8 @@ class BEMPipeline:
     def select(psnr_rows: List[float]) -> int:
         """eval.py:284-285 with psnr_weight = 1: index of the first maximum of psnr / max(psnr)."""
         m = max(psnr_rows)
+        if m == 0:                 # no usable score (no targets): the first candidate, like the reference's empty-score fallback
+            return 0
         rel = [p / m for p in psnr_rows]
         return rel.index(max(rel))
 
@@ -102,31 +105,3 @@ def build_nets(n_feat=40, num_blocks=(2, 2, 2), seed=100, device="cuda", stage2=
     convert2bnn_selective(net1, {"sigma_init": 0.05, "decay": 0.998, "pretrain": False})
     net2 = build_network(dict(type=stage2, in_channels=6, out_channels=3, decomp_model=decomp, **common))
     return net1.to(device).eval(), net2.to(device).eval()
-
-
-def smoke_check(verbose=False):
-    """1 image 60x52 (exercises reflect pad + crop), N = 2, reduced width, injected eps/noise:
-    HIP pipeline vs oracle.eval_mc_ref.  Raises AssertionError on mismatch."""
-    import numpy as np
-    from oracle import bem_oracle as O
-    net1, net2 = build_nets(n_feat=16, num_blocks=(1, 1, 1), seed=100, device="cuda")
-    sd1 = {k: v.detach().cpu() for k, v in net1.state_dict().items()}
-    sd2 = {k: v.detach().cpu() for k, v in net2.state_dict().items()}
-    lq, gt = synthetic_pair((1, 3, 60, 52))
-    N = 2
-    g = torch.Generator().manual_seed(7)
-    eps_cpu = [{k[:-len("mu_weight")] + "weight" if k.endswith("mu_weight") else k[:-len("mu_bias")] + "bias": torch.randn(v.shape, generator=g)
-                for k, v in sd1.items() if k.endswith(("mu_weight", "mu_bias"))} for _ in range(N)]
-    noise = torch.randn(N, 3, 4, 4, generator=g)
-    ref = O.eval_mc_ref(sd1, sd2, lq, gt, N, eps_list=eps_cpu, noise_list=[noise[i:i + 1] for i in range(N)], scan=O.selective_scan_c)
-    eps_dev = {k: torch.stack([e[k] for e in eps_cpu]).cuda() for k in eps_cpu[0]}
-    pipe = BEMPipeline(net1, net2)
-    out = pipe.enhance(lq.cuda(), gt.cuda(), N, gt_mean=True, eps=eps_dev, noise=noise.cuda())
-    fin = out["final"].cpu()
-    err = max(float((fin[i].permute(1, 2, 0) - torch.from_numpy(ref["finals"][i])).abs().max()) for i in range(N))
-    dps = float(np.abs(np.array(ref["psnr"]) - out["psnr"].cpu().numpy()).max())
-    if verbose:
-        print(f"smoke: candidates max|diff| = {err:.2e}, max PSNR diff = {dps:.2e} dB, best {out['best'][0]} (oracle {ref['best']})")
-    assert err < 5e-4 and dps < 1e-3, (err, dps)
-    assert out["best"][0] == ref["best"]
-    return err, dps

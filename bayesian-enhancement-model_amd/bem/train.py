@@ -1,0 +1,97 @@
+"""Optimizer side of the Stage-II training step (basicsr/models/image_enhancer_model.py:200-211):
+``clip_grad_norm_(net.parameters(), max_norm)`` + ``torch.optim.AdamW.step()`` as two kernel launches over ONE flat buffer.
+
+All trainable parameters of a group live in one contiguous f32 buffer (``p.data`` are views of it), their gradients in a second
+one (``p.grad`` are views; the backward kernels of bem.autograd accumulate straight into them), Adam's moments in two more:
+  zero_grad  = one memset,
+  clip       = one sum-of-squares reduction (f64) whose result stays on the device,
+  step       = one elementwise kernel that reads the clip coefficient from the device -- no host synchronisation in the step.
+Hyper-parameters, update rule and state layout follow torch.optim.AdamW (decoupled weight decay, bias correction), so a
+``state_dict()`` from here loads into torch.optim.AdamW and back.
+"""
+from __future__ import annotations
+
+from typing import Iterable
+
+import torch
+
+from . import ops
+
+
+def _align4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+class BemAdamW(torch.optim.Optimizer):
+    def __init__(self, params: Iterable, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, **ignored):
+        defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self._flat = []          # per group: dict(p, g, m, v, n, params)
+        self._steps = 0
+        self._max_norm = 0.0
+        self._sumsq = None
+        self._norm = None
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.requires_grad]
+            if not ps:
+                self._flat.append(None)
+                continue
+            dev = ps[0].device
+            if dev.type != "cuda" or any(p.device != dev or p.dtype != torch.float32 for p in ps):
+                raise ValueError("BemAdamW: float32 parameters on one HIP device")
+            total = sum(_align4(p.numel()) for p in ps)
+            fp = torch.zeros(total, device=dev, dtype=torch.float32)
+            fg = torch.zeros_like(fp)
+            fm, fv = torch.zeros_like(fp), torch.zeros_like(fp)
+            off = 0
+            with torch.no_grad():
+                for p in ps:
+                    n = p.numel()
+                    fp[off:off + n].copy_(p.detach().reshape(-1))
+                    p.data = fp[off:off + n].view(p.shape)
+                    p.grad = fg[off:off + n].view(p.shape)
+                    self.state[p] = {"step": torch.tensor(0.0), "exp_avg": fm[off:off + n].view(p.shape), "exp_avg_sq": fv[off:off + n].view(p.shape)}
+                    off += _align4(n)
+            self._flat.append(dict(p=fp, g=fg, m=fm, v=fv, params=ps))
+            self._sumsq = torch.zeros(1, device=dev, dtype=torch.float64)
+            self._norm = torch.zeros(1, device=dev, dtype=torch.float32)
+        ops.bump_weight_epoch()
+
+    # -- gradient buffers -------------------------------------------------------------------------------------------
+    def zero_grad(self, set_to_none: bool = False):
+        """One memset per group; the .grad views stay attached (set_to_none is ignored: the kernels accumulate into them)."""
+        for f in self._flat:
+            if f is None:
+                continue
+            f["g"].zero_()
+            off = 0
+            for p in f["params"]:
+                n = p.numel()
+                if p.grad is None or p.grad.data_ptr() != f["g"].data_ptr() + 4 * off:
+                    p.grad = f["g"][off:off + n].view(p.shape)
+                off += _align4(n)
+
+    def clip_grad_norm_(self, max_norm: float):
+        """torch.nn.utils.clip_grad_norm_ over every group's gradients (L2, error_if_nonfinite=False).  The scaling happens inside
+        the next step(); returns a 1-element device tensor that holds the total norm once that step has run."""
+        flats = [f for f in self._flat if f is not None]
+        if len(flats) != 1:
+            raise NotImplementedError("BemAdamW.clip_grad_norm_: one non-empty parameter group")
+        ops.grad_sumsq(flats[0]["g"], self._sumsq)
+        self._max_norm = float(max_norm)
+        return self._norm
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError("BemAdamW.step: closures are not supported")
+        self._steps += 1
+        for group, f in zip(self.param_groups, self._flat):
+            if f is None:
+                continue
+            ops.adamw_step_(f["p"], f["g"], f["m"], f["v"], group["lr"], group["betas"], group["eps"], group["weight_decay"], self._steps,
+                            max_norm=self._max_norm, sumsq=self._sumsq if self._max_norm > 0 else None, norm_out=self._norm)
+            for p in f["params"]:
+                self.state[p]["step"] += 1
+        self._max_norm = 0.0
+        ops.bump_weight_epoch()        # parameters changed behind torch's version counters: derived-weight caches are stale

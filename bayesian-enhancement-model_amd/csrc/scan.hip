@@ -7,110 +7,11 @@
 // h -> P*h + S, the 64 lanes of a wave compose their maps with wavefront shuffles (Hillis-Steele,
 // 6 steps), waves exchange their aggregates through LDS and a running carry links successive chunks.
 // The reverse directions use the mirrored lane / wave / element order of the same code.
-#include "bem_common.h"
+#include "scan_common.h"
 #include <cstdlib>
 
 namespace {
 
-template <bool REV>
-__device__ __forceinline__ float shfl_prev(float v, int d) {
-    return REV ? __shfl_down(v, d, BEM_WAVE) : __shfl_up(v, d, BEM_WAVE);
-}
-
-// Block-wide composition of per-thread affine maps.  On entry (a[e], b[e]) are the per-position
-// coefficients h_t = a_t * h_prev + b_t of this thread's E positions (identity = (1, 0) for padding).
-// On exit h[e] holds the state after position e; `carry` (state entering the chunk, uniform) is updated
-// to the state leaving the chunk.  agg is LDS scratch of 2*NW floats; contains two barriers.
-// block_scan_enter returns the state entering this thread's first position (in scan order) and advances `carry`.
-template <int NT, int E, bool REV>
-__device__ __forceinline__ float block_scan_enter(const float (&a)[E], const float (&b)[E], float& carry, float* agg) {
-    constexpr int NW = NT / BEM_WAVE;
-    const int lane = threadIdx.x & (BEM_WAVE - 1);
-    const int wave = threadIdx.x / BEM_WAVE;
-    const int rl = REV ? (BEM_WAVE - 1 - lane) : lane;   // logical lane in scan order
-    float P = 1.f, S = 0.f;
-#pragma unroll
-    for (int i = 0; i < E; ++i) {
-        const int e = REV ? (E - 1 - i) : i;
-        S = a[e] * S + b[e];
-        P = P * a[e];
-    }
-    // inclusive wave scan of (P, S): compose(prev, cur) = (Pp*Pc, Pc*Sp + Sc)
-#pragma unroll
-    for (int d = 1; d < BEM_WAVE; d <<= 1) {
-        const float Pp = shfl_prev<REV>(P, d);
-        const float Sp = shfl_prev<REV>(S, d);
-        if (rl >= d) {
-            S = P * Sp + S;
-            P = P * Pp;
-        }
-    }
-    float Pe = shfl_prev<REV>(P, 1);
-    float Se = shfl_prev<REV>(S, 1);
-    if (rl == 0) { Pe = 1.f; Se = 0.f; }
-    if (NW > 1) {
-        if (rl == BEM_WAVE - 1) { agg[2 * wave] = P; agg[2 * wave + 1] = S; }
-        __syncthreads();
-    }
-    float hw = carry;      // state entering this wave
-    float hend = carry;    // state leaving the chunk
-    if (NW > 1) {
-        const int rw = REV ? (NW - 1 - wave) : wave;
-#pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            const int w = REV ? (NW - 1 - i) : i;
-            const float Pw = agg[2 * w], Sw = agg[2 * w + 1];
-            hend = Pw * hend + Sw;
-            if (i < rw) hw = Pw * hw + Sw;
-        }
-        __syncthreads();   // agg may be rewritten by the next call
-    } else {
-        // single wave: total = inclusive value of the last logical lane
-        const float Pt = __shfl(P, REV ? 0 : BEM_WAVE - 1, BEM_WAVE);
-        const float St = __shfl(S, REV ? 0 : BEM_WAVE - 1, BEM_WAVE);
-        hend = Pt * carry + St;
-    }
-    carry = hend;
-    return Pe * hw + Se;       // state entering this thread
-}
-
-template <int NT, int E, bool REV>
-__device__ __forceinline__ void block_scan_affine(const float (&a)[E], const float (&b)[E], float (&h)[E],
-                                                  float& carry, float* agg) {
-    float hh = block_scan_enter<NT, E, REV>(a, b, carry, agg);
-#pragma unroll
-    for (int i = 0; i < E; ++i) {
-        const int e = REV ? (E - 1 - i) : i;
-        hh = a[e] * hh + b[e];
-        h[e] = hh;
-    }
-}
-
-template <int E>
-__device__ __forceinline__ void load_row(const float* __restrict__ p, int64_t t0, int L, bool vec, float (&v)[E]) {
-    if (vec && t0 + E <= L) {
-#pragma unroll
-        for (int i = 0; i < E; i += 4) {
-            const float4 q = *reinterpret_cast<const float4*>(p + t0 + i);
-            v[i] = q.x; v[i + 1] = q.y; v[i + 2] = q.z; v[i + 3] = q.w;
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < E; ++i) v[i] = (t0 + i < L) ? p[t0 + i] : 0.f;
-    }
-}
-template <int E>
-__device__ __forceinline__ void store_row(float* __restrict__ p, int64_t t0, int L, bool vec, const float (&v)[E]) {
-    if (vec && t0 + E <= L) {
-#pragma unroll
-        for (int i = 0; i < E; i += 4)
-            *reinterpret_cast<float4*>(p + t0 + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
-    } else {
-#pragma unroll
-        for (int i = 0; i < E; ++i)
-            if (t0 + i < L) p[t0 + i] = v[i];
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // General selective scan (any dstate, groups): one workgroup per (batch, channel) row.
@@ -182,19 +83,6 @@ __global__ __launch_bounds__(NT) void selective_scan_fwd_kernel(
 // a_{t+1} of a thread's last element is recomputed from delta[t+1] (one extra exp per thread) instead of being
 // exchanged between lanes.
 // ------------------------------------------------------------------------------------------------
-template <int NT>
-__device__ __forceinline__ float block_reduce_sum(float v, float* sh) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, BEM_WAVE);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __syncthreads();
-    if (lane == 0) sh[wave] = v;
-    __syncthreads();
-    float s = 0.f;
-#pragma unroll
-    for (int w = 0; w < NT / BEM_WAVE; ++w) s += sh[w];
-    return s;
-}
 
 template <int NT, int E>
 __global__ __launch_bounds__(NT) void selective_scan_bwd_kernel(
@@ -914,7 +802,7 @@ extern "C" int bem_ss2d_scan_strided_f32(const float* x0, const float* x1, const
                                          const float* dtw, const float* dtb, const float* A, const float* Ds, float* y0,
                                          float* y1, int B, int C, int L, int R, int64_t xd0_bstride, int64_t xd1_bstride, void* stream) {
     const int64_t xbs0 = xd0_bstride ? xd0_bstride : (int64_t)2 * (R + 2) * L, xbs1 = xd1_bstride ? xd1_bstride : (int64_t)2 * (R + 2) * L;
-    BEM_REQUIRE(xbs0 >= (int64_t)2 * (R + 2) * L && xbs1 >= (int64_t)2 * (R + 2) * L && xbs0 % 4 == 0 && xbs1 % 4 == 0, "ss2d_scan: x_dbl batch strides");
+    BEM_REQUIRE(xbs0 >= (int64_t)2 * (R + 2) * L && xbs1 >= (int64_t)2 * (R + 2) * L && (L % 4 != 0 || (xbs0 % 4 == 0 && xbs1 % 4 == 0)), "ss2d_scan: x_dbl batch strides");
     BEM_REQUIRE(x0 && x1 && xd0 && xd1 && dtw && dtb && A && Ds && y0 && y1, "ss2d_scan: null tensor");
     BEM_REQUIRE(B >= 0 && C > 0 && L >= 0 && R >= 1 && (int64_t)B * C * 2 < (1ll << 31), "ss2d_scan: bad shape B=%d C=%d L=%d R=%d", B, C, L, R);
     if (B == 0 || L == 0) return BEM_OK;

@@ -1,20 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- images/s of the two-stage N = 8 Bayesian enhancement eval at 256x256 (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  python bench.py --gpus N --steps K --warmup W [--config eval|train]
+  N > 1: either launched by `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...` (RANK /
+  WORLD_SIZE in the environment), or started plainly -- then this process spawns that launcher itself BEFORE touching the GPU
+  and relays rank 0's JSON line.
 
-One step = one pass of the hot path over one batch of synthetic input PER RANK:
-  8 images (256x256, LOL-like dark) x 8 Stage-I weight samples -> 64 conditions -> 64 Stage-II forwards
-  -> GT-mean + PSNR per candidate -> per-image selection; for N > 1 the candidates of all ranks are
-  all-gathered over RCCL (xGMI) so every rank holds every image's candidates (weak scaling).
-Inputs are resident in HBM before the timed region; weights are seeded random init of the full architecture
-(n_feat 40, blocks [2,2,2], shipped QD model4 decomposition weights).  f32 tensors throughout; the pointwise GEMMs evaluate
-their f32 products as six bf16-limb products with f32 accumulation (pw_gemm_x6.hip: error below torch's own f32 GEMM).
+--config eval (default; BASELINE configs[2]).  One step = one pass of the hot path over one batch PER RANK:
+  8 images (256x256, LOL-like dark) x 8 Stage-I weight samples -> 64 conditions -> 64 Stage-II forwards -> GT-mean + PSNR per
+  candidate -> per-image selection; for N > 1 the candidates + scores of all ranks are all-gathered over RCCL (xGMI) and the
+  selection runs on the gathered set (weak scaling: every rank its own 8 images).
+--config train (BASELINE configs[3]).  One step = ImageEnhancer.optimize_parameters on 16 synthetic 256x256 pairs:
+  condition noise + x16 upsample, Stage-II forward, L1, backward, global-norm clip, AdamW (image_enhancer_model.py:165-216).
+
+Inputs are resident in HBM before the timed region; weights are seeded random init of the full architecture (n_feat 40, blocks
+[2,2,2], shipped QD model4 decomposition weights).  f32 tensors throughout; the pointwise GEMMs of the forward evaluate their f32
+products as six bf16-limb products with f32 accumulation (pw_gemm_x6.hip: error below torch's own f32 GEMM).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -24,48 +30,127 @@ for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import torch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense f32 MFMA peak (MI355X_MICROARCH.md)
+BYTES_STAGE2_PER_PIXEL = 32360.0 / 4        # algorithmic bytes of one Stage-II forward per padded input pixel
+BYTES_STAGE1_PER_SAMPLE = 11.1e6
 
 
-def cpu_baseline(n_samples_timed=2, num_samples=8):
-    """The CPU oracle ("port": this repo's restatement of the reference's PyTorch-CPU path, including the
-    per-time-step Python loop of selective_scan_torch) on a bounded sample of the same workload."""
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", choices=("eval", "train"), default="eval")
+    ap.add_argument("--images", type=int, default=None, help="images per rank per step (default 8 eval / 16 train)")
+    ap.add_argument("--samples", type=int, default=8, help="Bayesian samples per image (eval)")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", choices=("candidates", "scores"), default="candidates",
+                    help="N > 1 exchange step: all candidates + scores (the north star's form) or scores + winners only")
+    ap.add_argument("--profile-kernel", default=None, help="op whose launches are timed with HIP events for the roofline entry (bem.ops._KEYS)")
+    return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """--gpus N without a launcher: start torch.distributed.run as a CHILD (this process has not initialised the GPU and never
+    replaces itself), relay its output, exit with its code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run(cmd, env=env)
+    sys.exit(r.returncode)
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_eval(num_samples=8):
+    """The CPU oracle ("port": this repo's restatement of the reference's PyTorch-CPU path, including the per-time-step Python loop
+    of selective_scan_torch) on BASELINE.md section 3's two protocols, bounded: (a) images at N = 1 (deterministic), (b) one image
+    with its N samples -- run on 2 of the N samples and scaled, since the N Stage-II forwards are identical work."""
+    import torch
     from oracle import bem_oracle as O
     from bem.pipeline import build_nets, synthetic_pair
     net1, net2 = build_nets(device="cpu")
     sd1 = {k: v.detach() for k, v in net1.state_dict().items()}
     sd2 = {k: v.detach() for k, v in net2.state_dict().items()}
-    lq, gt = synthetic_pair((1, 3, 256, 256))
+    lq, gt = synthetic_pair((2, 3, 256, 256))
     cores = torch.get_num_threads()
     t0 = time.perf_counter()
-    O.eval_mc_ref(sd1, sd2, lq, gt, n_samples_timed, gt_mean=True, scan=O.selective_scan_ref,
-                  generator=torch.Generator().manual_seed(0))
+    O.eval_mc_ref(sd1, sd2, lq[:1], gt[:1], 1, gt_mean=True, deterministic=True, scan=O.selective_scan_ref, generator=torch.Generator().manual_seed(0))
+    t_n1 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    O.eval_mc_ref(sd1, sd2, lq[1:], gt[1:], 2, gt_mean=True, scan=O.selective_scan_ref, generator=torch.Generator().manual_seed(0))
+    t_2 = time.perf_counter() - t0
+    per_image = t_2 * num_samples / 2
+    return {"value": 1.0 / per_image, "unit": "img/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "value_n1": 1.0 / t_n1,
+            "sample": f"(a) 1 image at N=1 deterministic: {t_n1:.1f} s; (b) 1 image x 2 of {num_samples} samples at 256x256: {t_2:.1f} s, scaled to "
+                      f"{num_samples} samples/image (BASELINE.md section 3 protocol (b); the full 8 x N=1 / 1 x N=8 passes would take minutes)"}
+
+
+def cpu_baseline_train():
+    """The oracle's training step (torch-CPU autograd through the restated net incl. the Python-loop scan) on ONE 128x128 pair,
+    scaled by pixels to 256x256 (the work is linear in pixels)."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import bem_oracle as O
+    from bem.pipeline import build_nets, synthetic_pair
+    _, net2 = build_nets(device="cpu")
+    sd = {k: v.detach() for k, v in net2.state_dict().items()}
+    lq, gt = synthetic_pair((1, 3, 128, 128))
+    gd = F.interpolate(gt, scale_factor=1 / 16, mode="bilinear")
+    cores = torch.get_num_threads()
+    t0 = time.perf_counter()
+    O.train_step_ref(sd, lq, gt, gd, steps=1)
     dt = time.perf_counter() - t0
-    per_image = dt * num_samples / n_samples_timed
-    return {"value": 1.0 / per_image, "unit": "img/s", "cores": cores, "kind": "port",
-            "sample": f"1 image x {n_samples_timed} of {num_samples} samples at 256x256 ({dt:.1f} s CPU), scaled to {num_samples} samples/image"}
+    return {"value": 1.0 / (dt * 4.0), "unit": "img/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "sample": f"1 training step on one 128x128 pair ({dt:.1f} s CPU), scaled x4 to 256x256"}
+
+
+def psnr_delta_check(dev):
+    """Outside the timed region: one small injected-epsilon Monte-Carlo enhancement on the GPU against the CPU oracle -- the
+    'PSNR delta vs ref' half of the metric (max over candidates, dB)."""
+    import torch
+    from oracle import bem_oracle as O
+    from bem.pipeline import BEMPipeline, build_nets, synthetic_pair
+    net1, net2 = build_nets(n_feat=16, num_blocks=(1, 1, 1), seed=100, device=dev)
+    sd1 = {k: v.detach().cpu() for k, v in net1.state_dict().items()}
+    sd2 = {k: v.detach().cpu() for k, v in net2.state_dict().items()}
+    lq, gt = synthetic_pair((1, 3, 64, 64))
+    N = 2
+    g = torch.Generator().manual_seed(7)
+    eps_cpu = [{(k[:-len("mu_weight")] + "weight" if k.endswith("mu_weight") else k[:-len("mu_bias")] + "bias"): torch.randn(v.shape, generator=g)
+                for k, v in sd1.items() if k.endswith(("mu_weight", "mu_bias"))} for _ in range(N)]
+    noise = torch.randn(N, 3, 4, 4, generator=g)
+    ref = O.eval_mc_ref(sd1, sd2, lq, gt, N, eps_list=eps_cpu, noise_list=[noise[i:i + 1] for i in range(N)], scan=O.selective_scan_c)
+    out = BEMPipeline(net1, net2).enhance(lq.to(dev), gt.to(dev), N, gt_mean=True, eps={k: torch.stack([e[k] for e in eps_cpu]).to(dev) for k in eps_cpu[0]},
+                                          noise=noise.to(dev))
+    return max(abs(a - b) for a, b in zip(ref["psnr"], out["psnr"].cpu().tolist()))
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--images", type=int, default=8, help="images per rank per step")
-    ap.add_argument("--samples", type=int, default=8, help="Bayesian samples per image")
-    ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-kernel", default="pw_x6_stream<2>", help="kernel whose launches are timed with HIP events for the roofline entry (bem.ops._KEYS)")
-    args = ap.parse_args()
-
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
@@ -75,19 +160,41 @@ def main():
 
     from bem import native, ops
     native.lib()      # fail loudly without the HIP library
-    from bem.dist import gather_candidates
+    from bem import dist as bdist
     from bem.pipeline import BEMPipeline, build_nets, synthetic_pair
 
-    net1, net2 = build_nets(device=dev)
-    pipe = BEMPipeline(net1, net2, 16, 0.1)
-    B, N, S = args.images, args.samples, args.size
+    S, N = args.size, args.samples
+    train = args.config == "train"
+    B = args.images or (16 if train else 8)
     lq, gt = synthetic_pair((B, 3, S, S), seed=287128 + rank, device=dev)     # every rank its own images
 
-    def step(i):
-        r = pipe.enhance(lq, gt, N, gt_mean=True, seed=1000 + i, sync=False)   # selection on the device, no host sync per step
-        if world > 1:
-            return gather_candidates(r["final"], r["psnr"], world)
-        return r["final"], r["psnr"]
+    if train:
+        from basicsr.models import build_model
+        from basicsr.utils.options import parse as parse_opt
+        opt = parse_opt(os.path.join(PKG, "Options", "DecompDualBranch2DDWavelet_4.yml"), is_train=True)
+        opt["dist"], opt["rank"], opt["world_size"] = world > 1, rank, world
+        torch.manual_seed(opt.get("manual_seed", 100))
+        model = build_model(opt)
+        gt_down = ops.resize_down(gt, opt["condition"]["scale_down"])
+        batch = dict(lq=lq, gt=gt, gt_down=gt_down)
+        it = [0]
+
+        def step(i):
+            it[0] += 1
+            model.update_learning_rate(it[0], warmup_iter=opt["train"].get("warmup_iter", -1))
+            model.feed_train_data(batch)
+            return model.optimize_parameters(it[0])
+        prof_key = args.profile_kernel or "pw_wgrad"
+    else:
+        net1, net2 = build_nets(device=dev)
+        pipe = BEMPipeline(net1, net2, 16, 0.1)
+
+        def step(i):
+            r = pipe.enhance(lq, gt, N, gt_mean=True, seed=1000 + i, sync=False, rank=rank)     # selection on the device, no host sync
+            if world > 1:
+                return bdist.exchange_and_select(r["final"], r["psnr"], N, world, mode=args.gather)
+            return r["best_images"], r["best"]
+        prof_key = args.profile_kernel or "pw_x6_stream<2>"
 
     def barrier():
         if world > 1:
@@ -96,7 +203,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    ops.profile_start(args.profile_kernel)
+    ops.profile_start(prof_key)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -111,44 +218,46 @@ def main():
 
     if rank == 0:
         imgs = world * B * args.steps
-        out = {
-            "metric": f"images/sec (whole node) CG_UNet N={N} Bayesian eval @{S}x{S}",
-            "value": imgs / dt, "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "arithmetic": "f32 storage and accumulation; pointwise GEMM products as exact 3-limb bf16 expansions (6 MFMA products, error <= torch f32 GEMM)",
-            "config": {"workload": f"CG_UNet_LOLv1.yml + DecompDualBranch2DDWavelet_4.yml eval, batch={B} {S}x{S}, N={N} Bayesian samples + GT_mean per GPU",
-                       "images_per_gpu": B, "samples_per_image": N, "parallelism": f"image-sharded x{world}, RCCL all-gather of candidates"},
-        }
-        # roofline of the dominant kernel, from HIP events recorded around its launches in the timed steps
+        out = {"value": imgs / dt, "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic"}
+        if train:
+            out["metric"] = f"images/sec (whole node) DecompDualBranchDDWavelet Stage-II training step (fwd+bwd+AdamW) @{S}x{S}"
+            out["arithmetic"] = "f32 storage and accumulation; forward / input-gradient 1x1 GEMMs as exact 3-limb bf16 expansions, weight gradients on f32 MFMA"
+            out["config"] = {"workload": f"DecompDualBranch2DDWavelet_4.yml training step (fwd+bwd+clip+AdamW), batch={B} {S}x{S} per GPU, L1 loss",
+                             "images_per_gpu": B, "parallelism": f"replicas x{world} (no gradient all-reduce: BASELINE config 4 is single-GPU)"}
+            bytes_img = 3.0 * BYTES_STAGE2_PER_PIXEL * S * S          # fwd + 2x for bwd on the same tensors
+        else:
+            out["metric"] = f"images/sec (whole node) CG_UNet N={N} Bayesian eval @{S}x{S}"
+            out["arithmetic"] = "f32 storage and accumulation; pointwise GEMM products as exact 3-limb bf16 expansions (6 MFMA products, error <= torch f32 GEMM)"
+            out["config"] = {"workload": f"CG_UNet_LOLv1.yml + DecompDualBranch2DDWavelet_4.yml eval, batch={B} {S}x{S}, N={N} Bayesian samples + GT_mean per GPU",
+                             "images_per_gpu": B, "samples_per_image": N,
+                             "parallelism": f"image-sharded x{world}, RCCL all-gather of {args.gather}" if world > 1 else "single GPU"}
+            bytes_img = N * (BYTES_STAGE2_PER_PIXEL * S * S + BYTES_STAGE1_PER_SAMPLE)
+            # decomp(image) does not depend on the sample: evaluated once per image here (hoisted).  SURVEY 8d asks for both figures.
+            hoist = (N - 1) * 43.0e6 * (S * S / 65536.0)
+            out["algorithmic_bytes_per_image"] = {"decomp_not_hoisted": bytes_img, "decomp_hoisted": bytes_img - hoist,
+                                                  "note": "path_hbm_roofline_frac uses the un-hoisted figure of SURVEY 8d"}
+        # roofline of the profiled kernel, from HIP events recorded around its launches in the timed steps
         if prof and prof["launches"]:
             avg_ms = prof["ms"] / prof["launches"]
+            rl = {"kernel": prof["kernel"], "bound": prof["bound"], "launches": prof["launches"], "avg_launch_us": avg_ms * 1e3,
+                  "algorithmic_bytes_per_launch": prof["bytes"] / prof["launches"], "traffic": None,
+                  "traffic_note": "HBM bytes from PMC counters need separate rocprofv3 --pmc passes: see profiles/r02_traffic*.json (not measured in this run)"}
             if prof["bound"] == "mfma":
                 ach = prof["flops"] / prof["launches"] / (avg_ms * 1e-3) / 1e12
-                out["roofline"] = {"kernel": prof["kernel"], "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                                   "launches": prof["launches"], "avg_launch_us": avg_ms * 1e3,
-                                   "hbm_GBps_algorithmic": prof["bytes"] / prof["launches"] / (avg_ms * 1e-3) / 1e9}
+                rl.update(achieved=ach, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / MFMA_F32_PEAK_TFLOPS,
+                          hbm_GBps_algorithmic=prof["bytes"] / prof["launches"] / (avg_ms * 1e-3) / 1e9)
             else:
                 ach = prof["bytes"] / prof["launches"] / (avg_ms * 1e-3) / 1e9
-                out["roofline"] = {"kernel": prof["kernel"], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": ach / HBM_PEAK_GBS, "traffic": None, "launches": prof["launches"], "avg_launch_us": avg_ms * 1e3}
-        # HBM traffic of that kernel from the PMC counters: rocprofv3 cannot be nested inside this process, so the per-launch
-        # figure is taken from the committed counter passes of this same command (profiles/r01_traffic.json, see its _note)
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"]
-            key = out["roofline"]["kernel"].replace("_kernel<", "_kernel<")
-            if key in tr and world == 1 and (B, N, S) == (8, 8, 256):
-                out["roofline"]["traffic"] = tr[key]["hbm_bytes_per_launch"]
-                out["roofline"]["algorithmic_bytes_per_launch"] = prof["bytes"] / prof["launches"]
-        except (OSError, KeyError, ValueError):
-            pass
-        # whole-path figure on SURVEY.md section 8d's algorithmic bytes: N * (32360 * Hp*Wp/4 + 11.1e6) per image
-        bytes_img = N * (32360.0 * S * S / 4 + 11.1e6)
+                rl.update(achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS)
+            out["roofline"] = rl
         out["path_hbm_roofline_frac"] = (out["value"] / world) * bytes_img / (HBM_PEAK_GBS * 1e9)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(2, N)
+            out["cpu_baseline"] = cpu_baseline_train() if train else cpu_baseline_eval(N)
             out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            if not train:
+                out["psnr_delta_db"] = psnr_delta_check(dev)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -275,6 +275,81 @@ int bem_gate_proj_x6_f32(const float* h, const float* dww, int64_t dww_bstride, 
                          const float* Wp, int64_t w_bstride, const float* bias, int64_t bias_bstride, const float* res,
                          float* out, int B, int Hd, int M, int H, int W, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Training step: backward of the Stage-II forward + optimizer, i.e. what
+ * `l_total.backward()`, clip_grad_norm_ and AdamW.step do in basicsr/models/image_enhancer_model.py:165-216.
+ * Gradient buffers of parameters (dw, dbias, dgamma, ...) are ACCUMULATED INTO (+=, float atomics) unless noted:
+ * the caller zeroes them once per step (optimizer.zero_grad()).
+ * ------------------------------------------------------------------------------------------- */
+
+/* L1Loss(loss_weight, reduction='mean') (basicsr/losses/losses.py:28): loss[0] (or NULL) = weight * mean |pred - gt|;
+ * dpred (or NULL) = gmul[0] * weight * sign(pred - gt) / n, gmul = device scalar dL/dloss (NULL = 1).
+ * ws: one double of scratch (zeroed by the call). */
+int bem_l1_loss_f32(const float* pred, const float* gt, float* dpred, float* loss, double* ws, int64_t n, float weight,
+                    const float* gmul, void* stream);
+
+/* Backward of bem_iwt_hamilton_f32: dout (B,3,2h,2w) -> dq1w, dq2w (B,16,h,w) (written). */
+int bem_iwt_hamilton_bwd_f32(const float* q1w, const float* q2w, const float* dout, float* dq1w, float* dq2w, int B, int h, int w,
+                             void* stream);
+
+/* nn.PixelUnshuffle(2): x (B,C,2H,2W) -> out (B,4C,H,W), out[c*4 + i*2 + j][y][x] = x[c][2y+i][2x+j] (H, W = OUTPUT plane size).
+ * Rearranges dL/dout of ConvTranspose2d(k=2,s=2) so that its input / weight gradients are 1x1 GEMMs, and is the inverse of
+ * bem_pixel_shuffle2_f32 (used for the input gradient of the 4x4 stride-2 convolution). */
+int bem_pixel_unshuffle2_f32(const float* x, float* out, int B, int C, int H, int W, void* stream);
+
+/* out[c] += sum over batch and pixels of x (B,C,L)  (bias gradients). */
+int bem_channel_sum_f32(const float* x, float* out, int B, int C, int64_t L, void* stream);
+/* out = a + alpha * b (n elements): gradient accumulation where a tensor feeds two consumers (encoder skips, shared
+ * bottleneck), and conds = gt_down + noise_level * randn of the training step (image_enhancer_model.py:143-148). */
+int bem_add_f32(const float* a, const float* b, float* out, int64_t n, float alpha, void* stream);
+
+/* LayerNorm2d backward (vmamba.py:58-63): x = x1 (+ x2 when non-NULL), all (B,C,L); dn = dL/dLN(x).
+ *   dx = (dres or 0) + LN'(dn)   written;   n_out (or NULL) = LN(x) written (the operand of the consumer's weight gradient);
+ *   dgamma, dbeta (C) accumulated. */
+int bem_ln_bwd_f32(const float* x1, const float* x2, const float* dn, const float* gamma, const float* beta, float eps,
+                   const float* dres, float* dx, float* n_out, float* dgamma, float* dbeta, int B, int C, int64_t L, void* stream);
+int bem_ln_fwd_f32(const float* x1, const float* x2, const float* gamma, const float* beta, float eps, float* n_out, int B, int C,
+                   int64_t L, void* stream);
+
+/* Backward of bem_dwconv3x3_f32 through the activation (modes 0 plain, 1 SiLU, 2 gdMlp gate), shared weights:
+ *   t (B,Cw,H,W) the conv input, dout (B,Cout,H,W); dpre (B,Cw,H,W) = dL/d(conv output + bias) written;
+ *   dw (Cw,9), dbias (Cw)|NULL accumulated.  The input gradient is bem_dwconv3x3_f32(dpre, flipped w, mode 0). */
+int bem_dwact_bwd_f32(const float* t, const float* w, const float* bias, const float* dout, float* dpre, float* dw, float* dbias,
+                      int B, int Cout, int H, int W, int mode, void* stream);
+
+/* Weight gradient of a 1x1 layer: dw[m][k] += sum_{b,p} dy[b][m][p] * x[b][k][p], x = x1 rows [0,C1) then x2 rows [C1,C1+C2)
+ * (the concat input mode of bem_pw_args; C2 = 0 / x2 = NULL otherwise); dbias[m] += sum dy[b][m][p] when non-NULL.
+ * *_bstride: elements between batch items (0 = contiguous).  dw row m is stored at row perm[m / blk_rows] * blk_rows + m % blk_rows
+ * with row stride ldw (blk_rows = 0: identity) -- lets the stacked x_proj GEMM of the fused SS2D write its per-direction blocks. */
+typedef struct {
+    const float* dy; int64_t dy_bstride; int M;
+    const float* x1; int64_t x1_bstride; int C1;
+    const float* x2; int64_t x2_bstride; int C2;
+    float* dw; int64_t ldw; int blk_rows; int perm[4];
+    float* dbias;
+    int B; int L;
+} bem_wgrad_args;
+int bem_pw_wgrad_f32(const bem_wgrad_args* a, void* stream);
+/* Weight (+ bias) gradient of the dense convolution of bem_conv2d_f32: dw (Cout,Cin,KH,KW) += dy (*) x, rows gathered on the
+ * fly (no im2col tensor); dy (B,Cout,Ho,Wo) contiguous, x (B,Cin,H,W) with batch stride x_bstride (0 = contiguous). */
+int bem_conv_wgrad_f32(const float* dy, const float* x, int64_t x_bstride, float* dw, float* dbias, int B, int Cin, int H, int W,
+                       int Cout, int KH, int KW, int stride, int pad, void* stream);
+
+/* Backward of bem_ss2d_scan_strided_f32 (same operand layout).  dy0 / dy1 = dL/dy0, dL/dy1; dx0 / dx1 written;
+ * dxd0 / dxd1 (B,2,R+2,L) contiguous: zeroed by the call, then accumulated over channels; dAlog (4C) = gradient of A_logs,
+ * dDs (4C), ddtw (4,C,R), ddtb (4,C) accumulated. */
+int bem_ss2d_scan_bwd_f32(const float* x0, const float* x1, const float* xd0, const float* xd1, const float* dy0, const float* dy1,
+                          const float* dtw, const float* dtb, const float* A, const float* Ds, float* dx0, float* dx1, float* dxd0,
+                          float* dxd1, float* dAlog, float* dDs, float* ddtw, float* ddtb, int B, int C, int L, int R,
+                          int64_t xd0_bstride, int64_t xd1_bstride, void* stream);
+
+/* clip_grad_norm_ + torch.optim.AdamW on one flat parameter buffer.  bem_grad_sumsq_f32: acc[0] = sum g^2 (f64, zeroed by the
+ * call).  bem_adamw_step_f32: g *= min(1, max_norm / (sqrt(sumsq) + 1e-6)) when max_norm > 0 (read on the device), then the AdamW
+ * update with bias corrections of `step` (>= 1); norm_out (or NULL) receives the unclipped total norm. */
+int bem_grad_sumsq_f32(const float* g, int64_t n, double* acc, void* stream);
+int bem_adamw_step_f32(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                       float weight_decay, int step, float max_norm, const double* sumsq, float* norm_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -553,3 +553,37 @@ def eval_mc_ref(sd1: SD, sd2: SD, img, target, num_samples, *, scale=16, noise_l
         rel = (np.array(psnrs) / max(psnrs)).tolist()      # eval.py:284 with psnr_weight=1
         best = rel.index(max(rel))
     return dict(img_down=img_down, conds=conds, preds=preds, finals=finals, psnr=psnrs, best=best)
+
+
+# ----------------------------------------------------------------------------------------------
+# A10  Stage-II training step      basicsr/models/image_enhancer_model.py:143-148,165-216
+#      (L1 pixel loss only: the perceptual term needs VGG19 weights that cannot be fetched here)
+# ----------------------------------------------------------------------------------------------
+
+def train_step_ref(sd: SD, lq, gt, conds, *, stage2=ddwavelet_ref, scale=16, lr=2e-4, betas=(0.9, 0.999), eps=1e-8,
+                   weight_decay=1e-4, max_grad_norm=1.0, steps=1, scan=selective_scan_ref):
+    """``optimize_parameters``: zero_grad -> up_conds = interpolate(conds, x scale) -> net_g(cat[lq, up_conds]) -> L1 ->
+    backward -> clip_grad_norm_(max_grad_norm) -> AdamW.step (optim_g of Options/DecompDualBranch2DDWavelet_4.yml:88-92).
+    ``sd``: the net's state dict; every key outside ``decomp.`` is trainable (the frozen decomposition is under no_grad,
+    DecompDualBranchDDWavelet_arch.py:307).  Returns per step the loss, the total gradient norm before clipping, the unclipped
+    gradients of the first step, and the parameters after the last step."""
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items() if not k.startswith("decomp.")}
+    frozen = {k: v.detach() for k, v in sd.items() if k.startswith("decomp.")}
+    opt = torch.optim.AdamW(list(params.values()), lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+    losses, norms, grads0 = [], [], None
+    for s in range(steps):
+        opt.zero_grad()
+        up = F.interpolate(conds, scale_factor=scale, mode="bilinear", align_corners=False)
+        out = stage2({**frozen, **params}, torch.cat([lq, up], 1), scan)
+        loss = (out - gt).abs().mean()
+        loss.backward()
+        if s == 0:
+            grads0 = {k: p.grad.detach().clone() for k, p in params.items()}
+        if max_grad_norm:
+            gn = torch.nn.utils.clip_grad_norm_(list(params.values()), max_grad_norm)
+        else:
+            gn = torch.sqrt(sum((p.grad ** 2).sum() for p in params.values()))
+        opt.step()
+        losses.append(float(loss))
+        norms.append(float(gn))
+    return dict(loss=losses, grad_norm=norms, grads=grads0, params={k: v.detach() for k, v in params.items()}, out=out.detach())

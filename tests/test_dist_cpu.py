@@ -50,3 +50,56 @@ def test_shard_images_partition():
         assert spans[0][0] == 0 and spans[-1][1] == n
         assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
         assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the real multi-GPU path: shard -> per-rank enhance -> exchange (both forms) -> selection == the unsharded result
+# ------------------------------------------------------------------------------------------------------------------
+def _stub_enhance(imgs, targets, num_samples, **kw):
+    """A deterministic stand-in with BEMPipeline.enhance's contract: candidate n of an image is a fixed function of the image
+    (so every rank can reproduce any other rank's candidates), score = PSNR against the target; ties are forced on image 1."""
+    b = imgs.shape[0]
+    N = num_samples
+    scale = torch.linspace(0.6, 1.4, N).view(1, N, 1, 1, 1)
+    final = (imgs[:, None] * scale).clamp(0, 1)
+    mse = ((final - targets[:, None]) ** 2).mean(dim=(2, 3, 4))
+    psnr = 10 * torch.log10(1 / mse)
+    psnr[imgs[:, 0, 0, 0] > 0.5] = 20.0                              # all-equal scores -> first index must win
+    return dict(final=final.reshape(b * N, *imgs.shape[1:]), psnr=psnr.reshape(b * N), N=N)
+
+
+def _sharded_worker(rank, world, port, n_images, N, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bem.dist import enhance_sharded
+    g = torch.Generator().manual_seed(3)
+    imgs = torch.rand(n_images, 3, 6, 5, generator=g) * 0.5
+    imgs[-1, 0, 0, 0] = 0.9                                          # the tie image
+    tg = (imgs * 1.2).clamp(0, 1)
+    full = _stub_enhance(imgs, tg, N)
+    s = full["psnr"].view(n_images, N)
+    ref_best = [row.index(max(row)) for row in s.tolist()]
+    ref_img = full["final"].view(n_images, N, 3, 6, 5)[torch.arange(n_images), torch.tensor(ref_best)]
+    ok = True
+    for mode in ("candidates", "scores"):
+        img, best = enhance_sharded(_stub_enhance, imgs, tg, N, rank, world, mode=mode)
+        ok = ok and best.tolist() == ref_best and torch.equal(img, ref_img)
+    ret[rank] = ok
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_images,N", [(4, 3), (5, 4), (1, 2)])
+def test_enhance_sharded_equals_unsharded_world2(n_images, N):
+    """Even shards, ragged shards, and fewer images than ranks (an empty shard joins the collectives)."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_sharded_worker, args=(world, 29650 + n_images, n_images, N, ret), nprocs=world, join=True)
+    assert all(ret[r] for r in range(world))
+
+
+def test_select_guards_all_zero_scores():
+    from bem.dist import select_best
+    assert select_best(torch.zeros(6), 3) == [0, 0]
+    # ties -> first index; a negative maximum flips the ratio order exactly as psnr / max(psnr) does in eval.py:284
+    assert select_best(torch.tensor([1.0, 3.0, 3.0, -2.0, -1.0, -1.0]), 3) == [1, 0]

@@ -1,0 +1,389 @@
+"""GPU parity of the training step: every backward kernel through the C ABI against torch-CPU
+autograd of the oracle's restatement of the same op, the VSSBlock / Stage-II gradients against the fixtures generated from the
+reference's own autograd (tests/golden/g4_vssblock.npz, g6_ddw.npz), and clip + AdamW against torch.optim.AdamW.
+
+Tolerances: f32 chains; gradients are compared per tensor as max|err| <= rtol * max|ref| + atol with the rtol written in each test
+(the reference's own kernel tests allow rtol 6e-4 .. 6e-3 / atol 2e-3 .. 2e-2 for f32 gradients, test_selective_scan.py:398-405,490-503)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, qd_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from bem import native
+    native.lib()
+    return torch.device("cuda", 0)
+
+
+def close(a, b, rtol, atol=0.0, what=""):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = float((a - b).abs().max())
+    ref = float(b.abs().max())
+    assert err <= rtol * ref + atol, f"{what}: max|err| {err:.3e} vs max|ref| {ref:.3e} (rtol {rtol}, atol {atol})"
+    return err
+
+
+def G(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+# ---------------------------------------------------------------------------------------------- small kernels
+def test_l1_loss_and_grad(dev):
+    from bem import ops
+    g = G(0)
+    for shape in ((2, 3, 17, 13), (1, 3, 64, 64)):
+        p, t = torch.rand(shape, generator=g), torch.rand(shape, generator=g)
+        p[0, 0, 0, 0] = t[0, 0, 0, 0]                       # sign(0) = 0
+        pr = p.clone().requires_grad_()
+        ref = 0.7 * (pr - t).abs().mean()
+        ref.backward(torch.tensor(2.5))
+        loss = ops.l1_loss(p.to(dev), t.to(dev), 0.7)
+        dp = ops.l1_loss_bwd(p.to(dev), t.to(dev), 0.7, torch.tensor([2.5], device=dev))
+        assert abs(float(loss) - float(ref)) <= 1e-6 * abs(float(ref))
+        close(dp, pr.grad, 1e-6, what="dpred")
+
+
+def test_iwt_hamilton_bwd(dev):
+    from bem import ops
+    from oracle import bem_oracle as O
+    g = G(1)
+    for (B, h, w) in ((2, 6, 5), (1, 16, 24)):
+        a = torch.randn(B, 16, h, w, generator=g, requires_grad=True)
+        b = torch.randn(B, 16, h, w, generator=g, requires_grad=True)
+        out = O.hamilton_ref(O.iwt_ref(a), O.iwt_ref(b))[:, 1:]
+        do = torch.randn(out.shape, generator=g)
+        out.backward(do)
+        fwd = ops.iwt_hamilton(a.detach().to(dev), b.detach().to(dev))
+        close(fwd, out, 1e-6, what="fwd")
+        d1, d2 = ops.iwt_hamilton_bwd(a.detach().to(dev), b.detach().to(dev), do.to(dev))
+        close(d1, a.grad, 2e-6, what="dq1w")
+        close(d2, b.grad, 2e-6, what="dq2w")
+
+
+def test_pixel_unshuffle_and_sums(dev):
+    from bem import ops
+    g = G(2)
+    x = torch.randn(2, 5, 6, 8, generator=g)
+    assert torch.equal(ops.pixel_unshuffle2(x.to(dev)).cpu(), F.pixel_unshuffle(x, 2))
+    assert torch.equal(ops.pixel_shuffle2(ops.pixel_unshuffle2(x.to(dev))).cpu(), x)
+    acc = torch.full((5,), 0.5, device=dev)
+    ops.channel_sum_(x.to(dev), acc)
+    close(acc, 0.5 + x.sum(dim=(0, 2, 3)), 1e-5, 1e-5, "channel_sum")
+    y = torch.randn(2, 5, 6, 8, generator=g)
+    close(ops.add(x.to(dev), y.to(dev), 0.25), x + 0.25 * y, 1e-7, what="add")
+
+
+@pytest.mark.parametrize("shape", [(2, 40, 16, 12), (1, 7, 9, 5), (2, 160, 8, 8), (1, 80, 33, 20)])
+@pytest.mark.parametrize("two", [False, True])
+def test_ln_bwd(dev, shape, two):
+    from bem import ops
+    g = G(3)
+    B, C, H, W = shape
+    x1 = torch.randn(shape, generator=g) * 2 + 0.5
+    x2 = torch.randn(shape, generator=g) if two else None
+    gam, bet = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    dn, dres = torch.randn(shape, generator=g), torch.randn(shape, generator=g)
+    xs = (x1 + x2 if two else x1).clone().requires_grad_()
+    gr, br = gam.clone().requires_grad_(), bet.clone().requires_grad_()
+    n = F.layer_norm(xs.permute(0, 2, 3, 1), (C,), gr, br, 1e-5).permute(0, 3, 1, 2)
+    n.backward(dn)
+    dgam, dbet = torch.full((C,), 1.0, device=dev), torch.zeros(C, device=dev)
+    dx, nn_ = ops.ln_bwd(x1.to(dev), dn.to(dev), gam.to(dev), bet.to(dev), 1e-5, dgam, dbet, x2=None if x2 is None else x2.to(dev), dres=dres.to(dev))
+    close(nn_, n, 2e-6, 2e-6, "LN(x)")
+    close(dx, xs.grad + dres, 1e-5, 1e-6, "dx")
+    close(dgam, 1.0 + gr.grad, 2e-5, 1e-5, "dgamma (accumulated onto 1)")
+    close(dbet, br.grad, 2e-5, 1e-5, "dbeta")
+    close(ops.ln_fwd(x1.to(dev), gam.to(dev), bet.to(dev), 1e-5, x2=None if x2 is None else x2.to(dev)), n, 2e-6, 2e-6, "ln_fwd")
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 16, 12), (1, 6, 9, 7), (2, 4, 32, 32), (1, 2, 5, 3)])
+@pytest.mark.parametrize("mode,bias", [(1, False), (1, True), (2, True), (0, True)])
+def test_dwact_bwd(dev, shape, mode, bias):
+    """dpre, the depthwise weight / bias gradients, and the input gradient = dwconv(dpre, flipped kernel)."""
+    from bem import ops
+    g = G(4)
+    B, Cw, H, W = shape
+    Cout = Cw // 2 if mode == 2 else Cw
+    t = torch.randn(shape, generator=g, requires_grad=True)
+    w = (torch.randn(Cw, 1, 3, 3, generator=g) * 0.4).requires_grad_()
+    b = (torch.randn(Cw, generator=g) * 0.3).requires_grad_() if bias else None
+    pre = F.conv2d(t, w, b, padding=1, groups=Cw)
+    pre.retain_grad()
+    if mode == 1:
+        out = F.silu(pre)
+    elif mode == 2:
+        a, c = pre.chunk(2, 1)
+        out = F.gelu(a) * c
+    else:
+        out = pre
+    do = torch.randn(B, Cout, H, W, generator=g)
+    out.backward(do)
+    close(ops.dwconv3x3(t.detach().to(dev), w.detach().to(dev), None if b is None else b.detach().to(dev), mode=mode), out, 5e-6, 1e-6, "forward")
+    dw = torch.zeros(Cw, 1, 3, 3, device=dev)
+    db = torch.zeros(Cw, device=dev) if bias else None
+    dpre = ops.dwact_bwd(t.detach().to(dev), w.detach().to(dev), None if b is None else b.detach().to(dev), do.to(dev), dw, db, mode)
+    close(dpre, pre.grad, 2e-5, 1e-6, "dpre")
+    close(dw, w.grad, 5e-5, 1e-5, "dw")
+    if bias:
+        close(db, b.grad, 5e-5, 1e-5, "dbias")
+    dt = ops.dwconv3x3(dpre, w.detach().flip(2, 3).contiguous().to(dev), None, mode=0)
+    close(dt, t.grad, 3e-5, 1e-6, "dt")
+
+
+@pytest.mark.parametrize("B,M,C1,C2,L", [(2, 40, 40, 0, 192), (1, 320, 40, 0, 1024), (2, 20, 40, 0, 77), (3, 80, 80, 80, 130), (1, 640, 160, 0, 64),
+                                         (2, 33, 7, 0, 31), (1, 160, 320, 0, 100), (2, 16, 64, 0, 256)])
+def test_pw_wgrad(dev, B, M, C1, C2, L):
+    from bem import ops
+    g = G(5)
+    dy = torch.randn(B, M, L, generator=g)
+    x1 = torch.randn(B, C1, L, generator=g)
+    x2 = torch.randn(B, C2, L, generator=g) if C2 else None
+    xx = torch.cat([x1, x2], 1) if C2 else x1
+    ref = torch.einsum("bml,bkl->mk", dy.double(), xx.double())
+    dw = torch.full((M, C1 + C2), 0.25, device=dev)
+    db = torch.zeros(M, device=dev)
+    ops.pw_wgrad_(dy.to(dev), x1.to(dev), dw, x2=None if x2 is None else x2.to(dev), dbias=db)
+    scale = float(ref.abs().max())
+    close(dw, 0.25 + ref, 0.0, 3e-6 * scale * max(1.0, (B * L) ** 0.5 / 8), "dw (accumulated onto 0.25)")
+    close(db, dy.double().sum(dim=(0, 2)), 0.0, 1e-5 * float(dy.abs().sum(dim=(0, 2)).max()), "dbias")
+
+
+def test_pw_wgrad_row_blocks_and_strided_dy(dev):
+    """The stacked x_proj form: dy is a channel slice of a wider tensor and the row blocks of dw are permuted ([0,2,1,3])."""
+    from bem import ops
+    g = G(6)
+    B, R2, C, L = 2, 5, 40, 192
+    wide = torch.randn(B, 4 * R2 + 3, L, generator=g)
+    x = torch.randn(B, C, L, generator=g)
+    ref = torch.einsum("bml,bkl->mk", wide[:, :4 * R2].double(), x.double()).view(4, R2, C)[[0, 2, 1, 3]]
+    dw = torch.zeros(4, R2, C, device=dev)
+    wd = wide.to(dev)
+    ops.pw_wgrad_(wd, x.to(dev), dw, blk_rows=R2, perm=(0, 2, 1, 3), dy_bstride=wd.stride(0), M=4 * R2)
+    close(dw, ref, 0.0, 1e-5 * float(ref.abs().max()), "permuted row blocks")
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,k,s,p", [(2, 8, 12, 10, 16, 3, 1, 1), (1, 32, 16, 16, 40, 3, 1, 1), (2, 16, 16, 12, 32, 4, 2, 1),
+                                                   (1, 40, 32, 32, 80, 4, 2, 1), (1, 3, 9, 7, 5, 3, 1, 1)])
+def test_conv_wgrad_and_input_grad(dev, B, Cin, H, W, Cout, k, s, p):
+    from bem import autograd as ag, ops
+    g = G(7)
+    x = torch.randn(B, Cin, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) * 0.2).requires_grad_()
+    b = torch.randn(Cout, generator=g, requires_grad=True)
+    out = F.conv2d(x, w, b, stride=s, padding=p)
+    do = torch.randn(out.shape, generator=g)
+    out.backward(do)
+    dw, db = torch.zeros(Cout, Cin, k, k, device=dev), torch.zeros(Cout, device=dev)
+    ops.conv_wgrad_(do.to(dev), x.detach().to(dev), dw, db, stride=s, pad=p)
+    close(dw, w.grad, 0.0, 2e-5 * float(w.grad.abs().max()), "dw")
+    close(db, b.grad, 0.0, 2e-5 * float(b.grad.abs().max()), "dbias")
+    wd = w.detach().to(dev)
+    if k == 3:
+        dx = ops.conv2d(do.to(dev), ag._wflip3(wd), None, stride=1, pad=1)
+    else:
+        dx = ops.pixel_shuffle2(ops.conv2d(do.to(dev), ag._wT4(wd), None, stride=1, pad=1))
+    close(dx, x.grad, 0.0, 3e-5 * float(x.grad.abs().max()), "dx")
+
+
+# ---------------------------------------------------------------------------------------------- fused SS2D backward
+def _ss2d_torch(x0, x1, xd0, xd1, dtw, dtb, A, Ds):
+    """The fused op restated with the oracle's scan (autograd-capable): returns y0 (row-major order), y1 (transposed order)."""
+    from oracle import bem_oracle as O
+    B, C, L = x0.shape
+    R = dtw.shape[2]
+    ys = []
+    for o, (x, xd) in enumerate(((x0, xd0), (x1, xd1))):
+        y = 0
+        for slot, k in enumerate((o, o + 2)):
+            rev = slot == 1
+            xs, d = (x.flip(-1), xd[:, slot].flip(-1)) if rev else (x, xd[:, slot])
+            dts = torch.einsum("cr,brl->bcl", dtw[k], d[:, :R])
+            yk = O.selective_scan_ref(xs, dts, A[k * C:(k + 1) * C].view(C, 1), d[:, R].reshape(B, 1, 1, L), d[:, R + 1].reshape(B, 1, 1, L),
+                                      Ds[k * C:(k + 1) * C], dtb[k], True)
+            y = y + (yk.flip(-1) if rev else yk)
+        ys.append(y)
+    return ys
+
+
+@pytest.mark.parametrize("B,C,L,R", [(2, 8, 192, 3), (1, 5, 77, 2), (1, 4, 1030, 1), (1, 3, 4100, 3), (1, 2, 9000, 2)])
+def test_ss2d_scan_bwd(dev, B, C, L, R):
+    from bem import ops
+    g = G(8)
+    x0 = torch.randn(B, C, L, generator=g, requires_grad=True)
+    x1 = torch.randn(B, C, L, generator=g, requires_grad=True)
+    xd0 = (torch.randn(B, 2, R + 2, L, generator=g) * 0.7).requires_grad_()
+    xd1 = (torch.randn(B, 2, R + 2, L, generator=g) * 0.7).requires_grad_()
+    dtw = (torch.randn(4, C, R, generator=g) * 0.5).requires_grad_()
+    dtb = (torch.randn(4, C, generator=g) * 0.5 - 1.0).requires_grad_()
+    Alog = (torch.rand(4 * C, 1, generator=g) - 1.5).requires_grad_()        # A = -exp(A_logs) in (-0.6, -0.2)
+    Ds = torch.randn(4 * C, generator=g, requires_grad=True)
+    A = -torch.exp(Alog).view(-1)
+    y0, y1 = _ss2d_torch(x0, x1, xd0, xd1, dtw, dtb, A, Ds)
+    dy0, dy1 = torch.randn(B, C, L, generator=g), torch.randn(B, C, L, generator=g)
+    (y0 * dy0).sum().add((y1 * dy1).sum()).backward()
+    d = lambda t: t.detach().to(dev).contiguous()
+    f0, f1 = ops.ss2d_scan(d(x0), d(x1), d(xd0), d(xd1), d(dtw), d(dtb), d(A), d(Ds))
+    close(f0, y0, 2e-4, 1e-5, "fwd y0"); close(f1, y1, 2e-4, 1e-5, "fwd y1")
+    dAl, dDs = torch.zeros(4 * C, device=dev), torch.zeros(4 * C, device=dev)
+    ddtw, ddtb = torch.zeros(4, C, R, device=dev), torch.zeros(4, C, device=dev)
+    dx0, dx1, dxd0, dxd1 = ops.ss2d_scan_bwd(d(x0), d(x1), d(xd0), d(xd1), d(dy0), d(dy1), d(dtw), d(dtb), d(A), d(Ds), dAl, dDs, ddtw, ddtb)
+    rt = 1e-3     # reference tolerance for f32 gradients: rtol 6e-4 .. 6e-3 (test_selective_scan.py:398-405)
+    close(dx0, x0.grad, rt, 1e-5, "dx0"); close(dx1, x1.grad, rt, 1e-5, "dx1")
+    close(dxd0, xd0.grad, rt, 1e-5, "dxd0"); close(dxd1, xd1.grad, rt, 1e-5, "dxd1")
+    close(dAl, Alog.grad.view(-1), rt, 1e-4, "dA_logs"); close(dDs, Ds.grad, rt, 1e-4, "dDs")
+    close(ddtw, dtw.grad, rt, 1e-4, "ddt_projs_weight"); close(ddtb, dtb.grad, rt, 1e-4, "ddt_projs_bias")
+
+
+# ---------------------------------------------------------------------------------------------- blocks and nets
+def test_vssblock_backward_golden(dev):
+    """VSSBlock C = 40 on 16x12: dx and the parameter gradients recorded from the REFERENCE's autograd (g4_vssblock.npz)."""
+    from bem.modules import VSSBlock
+    g = load_golden("g4_vssblock")
+    blk = VSSBlock(hidden_dim=40, ssm_d_state=1, ssm_ratio=1, ssm_conv_bias=False, forward_type="v05_noz", mlp_ratio=4, mlp_type="gdmlp",
+                   channel_first=True).to(dev)
+    blk.load_state_dict(g["sd"], strict=True)
+    blk.train()
+    x = g["x"].to(dev).requires_grad_()
+    y = blk(x)
+    close(y, g["y"], 2e-5, 1e-5, "forward")
+    y.backward(g["dout"].to(dev))
+    close(x.grad, g["dx"], 1e-3, 1e-5, "dx")
+    params = dict(blk.named_parameters())
+    for k, ref in g["grads"].items():
+        close(params[k].grad, ref, 2e-3, 1e-5 * float(ref.abs().max()) + 1e-7, k)
+
+
+def test_vssblock_backward_all_grads_vs_oracle(dev):
+    """Every parameter gradient of the block against autograd through the oracle (pinned to the reference by the test above
+    and by tests/test_oracle_golden.py), on a plane with odd sizes (general kernels) and on 32x32 (row-major scan form)."""
+    from bem.modules import VSSBlock
+    from oracle import bem_oracle as O
+    sd0 = load_golden("g4_vssblock")["sd"]
+    for (H, W), seed in (((9, 7), 11), ((32, 32), 12)):
+        g = G(seed)
+        blk = VSSBlock(hidden_dim=40, ssm_d_state=1, ssm_ratio=1, ssm_conv_bias=False, forward_type="v05_noz", mlp_ratio=4, mlp_type="gdmlp",
+                       channel_first=True).to(dev)
+        blk.load_state_dict(sd0, strict=True)
+        blk.train()
+        x = torch.randn(2, 40, H, W, generator=g)
+        do = torch.randn(2, 40, H, W, generator=g)
+        sd = {k: v.clone().requires_grad_() for k, v in sd0.items()}
+        xr = x.clone().requires_grad_()
+        O.vssblock_ref(sd, "", xr).backward(do)
+        xd = x.to(dev).requires_grad_()
+        blk(xd).backward(do.to(dev))
+        close(xd.grad, xr.grad, 1e-3, 1e-5, "dx")
+        for k, p in blk.named_parameters():
+            ref = sd[k].grad
+            close(p.grad, ref, 3e-3, 2e-5 * float(ref.abs().max()) + 1e-7, f"{H}x{W} {k}")
+
+
+def _load_stage2(name, g, dev, n_feat=16, num_blocks=(2, 1, 1), decomp="model4"):
+    from basicsr.archs import build_network
+    net = build_network(dict(type=name, in_channels=6, out_channels=3, n_feat=n_feat, d_state=[1, 1, 1], ssm_ratio=1, mlp_ratio=4, mlp_type="gdmlp",
+                             use_pixelshuffle=True, drop_path=0.0, sam=False, stage=1, num_blocks=list(num_blocks), decomp_model=decomp))
+    missing, unexpected = net.load_state_dict(g["sd"], strict=False)
+    assert not unexpected and all(k.startswith("decomp.") for k in missing), (missing, unexpected)
+    return net.to(dev)
+
+
+def test_stage2_training_gradients_golden(dev):
+    """DecompDualBranchDDWavelet (reduced width) 1x6x64x64, L1 loss: loss, total gradient norm and the recorded gradients of the
+    REFERENCE's training step (g6_ddw.npz), then every gradient against the oracle's autograd."""
+    from bem import autograd as ag
+    from oracle import bem_oracle as O
+    g = load_golden("g6_ddw")
+    net = _load_stage2("DecompDualBranchDDWavelet", g, dev)
+    net.train()
+    x, gt = g["x"].to(dev), g["gt"].to(dev)
+    out = net(x)[-1]
+    close(out, g["out"], 2e-4, 2e-5, "forward (train mode)")
+    loss = ag.l1_loss(out, gt)
+    assert abs(float(loss) - float(g["loss"])) < 2e-6
+    loss.backward()
+    named = {k: p for k, p in net.named_parameters() if p.requires_grad}
+    assert all(p.grad is not None for p in named.values())
+    gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in named.values())))
+    assert abs(gn - float(g["grad_norm"])) < 2e-4 * float(g["grad_norm"]), (gn, float(g["grad_norm"]))
+    sd = {**{k: v.clone().requires_grad_() for k, v in g["sd"].items()}, **qd_state_dict("model4")}
+    (O.ddwavelet_ref(sd, g["x"]) - g["gt"]).abs().mean().backward()
+    gmax = max(float(sd[k].grad.abs().max()) for k in named)
+    worst = 0.0
+    for k, p in named.items():
+        ref = sd[k].grad
+        # per tensor: 0.5 % of its own largest entry, floored at 1e-5 of the largest gradient entry of the net
+        worst = max(worst, close(p.grad, ref, 5e-3, 1e-5 * gmax, k) / (float(ref.abs().max()) + 1e-5 * gmax))
+    for k, ref in g["grads"].items():
+        close(named[k].grad, ref, 5e-3, 1e-5 * gmax, "reference fixture " + k)
+    print(f"stage-II gradients: worst per-tensor relative error {worst:.2e}, grad norm {gn:.6f} (reference {float(g['grad_norm']):.6f})")
+
+
+def test_adamw_and_clip_match_torch(dev):
+    from bem.train import BemAdamW
+    g = G(20)
+    shapes = [(7, 5), (33,), (4, 3, 3, 3), (1,), (128, 40)]
+    ps_ref = [torch.randn(s, generator=g).requires_grad_() for s in shapes]
+    ps = [torch.nn.Parameter(p.detach().clone().to(dev)) for p in ps_ref]
+    ref = torch.optim.AdamW(ps_ref, lr=2e-3, betas=(0.9, 0.999), weight_decay=1e-2)
+    opt = BemAdamW(ps, lr=2e-3, betas=(0.9, 0.999), weight_decay=1e-2)
+    for step in range(4):
+        ref.zero_grad(); opt.zero_grad()
+        for pr, pd in zip(ps_ref, ps):
+            gr = torch.randn(pr.shape, generator=g) * (3.0 if step % 2 == 0 else 0.01)     # clipping active / inactive
+            pr.grad = gr.clone()
+            pd.grad.copy_(gr.to(dev))
+        n_ref = torch.nn.utils.clip_grad_norm_(ps_ref, 1.0)
+        n_dev = opt.clip_grad_norm_(1.0)
+        ref.step(); opt.step()
+        assert abs(float(n_dev) - float(n_ref)) <= 1e-5 * float(n_ref)
+        for pr, pd in zip(ps_ref, ps):
+            close(pd, pr, 2e-6, 1e-7, f"step {step} parameter")
+            close(pd.grad, pr.grad, 2e-6, 1e-8, f"step {step} clipped gradient")
+
+
+def test_image_enhancer_train_step_matches_oracle(dev):
+    """ImageEnhancer.optimize_parameters (registry seam, option-file driven) for two steps against the oracle's restatement of
+    image_enhancer_model.py:165-216 on the same weights, inputs and conditions: loss, gradient norm, parameters after the steps."""
+    from basicsr.models import build_model
+    from oracle import bem_oracle as O
+    g = load_golden("g6_ddw")
+    opt = dict(model_type="ImageEnhancer", is_train=True, num_gpu=1, dist=False, condition=dict(type="mean", scale_down=16, noise_level=0.0),
+               network_g=dict(type="DecompDualBranchDDWavelet", in_channels=6, out_channels=3, n_feat=16, d_state=[1, 1, 1], ssm_ratio=1, mlp_ratio=4,
+                              mlp_type="gdmlp", use_pixelshuffle=True, drop_path=0.0, sam=False, stage=1, num_blocks=[2, 1, 1], decomp_model="model4"),
+               path=dict(pretrain_network_g=None, strict_load_g=True, resume_state=None),
+               train=dict(total_iter=10, warmup_iter=-1, max_grad_norm=1, use_amp=False,
+                          scheduler=dict(type="CosineAnnealingRestartCyclicLR", periods=[6, 4], restart_weights=[1, 1], eta_mins=[0.0002, 0.000001]),
+                          optim_g=dict(type="AdamW", lr=2e-4, weight_decay=1e-4, betas=[0.9, 0.999]),
+                          pixel_opt=dict(type="L1Loss", loss_weight=1, reduction="mean")))
+    lq, gt = g["x"][:, :3], g["gt"]
+    gen = G(33)
+    gt_down = F.interpolate(gt, scale_factor=1 / 16, mode="bilinear") + 0.1 * torch.randn(1, 3, 4, 4, generator=gen)
+    sd = {**g["sd"], **qd_state_dict("model4")}
+    ref = O.train_step_ref(sd, lq, gt, gt_down, steps=2, lr=2e-4, weight_decay=1e-4, max_grad_norm=1.0)
+    model = build_model(opt)                 # is_train: the flat parameter / gradient buffers exist from here on
+    model.net_g.load_state_dict(g["sd"], strict=False)      # copies into the flat buffer's views
+    for it in range(2):
+        model.feed_train_data(dict(lq=lq, gt=gt, gt_down=gt_down))
+        tn = model.optimize_parameters(it + 1)
+        assert abs(float(model.log_dict["l_pix"]) - ref["loss"][it]) < 3e-6, (it, float(model.log_dict["l_pix"]), ref["loss"][it])
+        assert abs(float(tn) - ref["grad_norm"][it]) < 5e-4 * ref["grad_norm"][it], (it, float(tn), ref["grad_norm"][it])
+    named = dict(model.net_g.named_parameters())
+    # Adam's first steps are sign-like (update = lr * g / (|g| + eps)): an element whose gradient is at rounding level may move the
+    # other way.  Hold the UPDATE (not just the weight) to 5 % on all but a small fraction of the elements, and every weight to
+    # the size of one full update.
+    bad = tot = 0
+    for k, v in ref["params"].items():
+        u_ref, u_dev = (v - sd[k]).double(), (named[k].detach().cpu() - sd[k]).double()
+        assert float((u_dev - u_ref).abs().max()) <= 2 * 2 * 2e-4 * 1.05, k
+        bad += int(((u_dev - u_ref).abs() > 0.05 * u_ref.abs() + 2e-6).sum())
+        tot += v.numel()
+    assert bad <= 0.01 * tot, f"{bad} of {tot} parameter updates differ from the oracle's"
