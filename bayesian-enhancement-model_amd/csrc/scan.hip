@@ -409,51 +409,6 @@ __global__ __launch_bounds__(NT) void ss2d_scan_full_kernel(
 // contiguous 1 KB segment; the wavefront scan runs on DPP row shifts / row broadcasts (no LDS traffic); y of both
 // directions accumulates in registers (x read twice, y written once).
 // ------------------------------------------------------------------------------------------------
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ float dpp_mov(float old, float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
-                                                                 CTRL, ROWMASK, 0xf, false));
-}
-__device__ __forceinline__ float lane_bcast(float v, int lane) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
-}
-#define BEM_SCAN_STEP(CTRL, RM)                                         \
-    {                                                                   \
-        const float Pp = dpp_mov<CTRL, RM>(1.f, P), Sp = dpp_mov<CTRL, RM>(0.f, S); \
-        S = fmaf(P, Sp, S);                                             \
-        P = P * Pp;                                                     \
-    }
-// inclusive scan of the per-lane affine maps (P, S) in ascending (REV = false) / descending (REV = true) lane order;
-// returns the exclusive map (Pe, Se) of every lane and leaves the wavefront total in lane 63 (0 for REV).
-template <bool REV>
-__device__ __forceinline__ void wave_scan_affine(float& P, float& S, float& Pe, float& Se) {
-    if (!REV) {
-        BEM_SCAN_STEP(0x111, 0xf) BEM_SCAN_STEP(0x112, 0xf) BEM_SCAN_STEP(0x114, 0xf) BEM_SCAN_STEP(0x118, 0xf)   // row_shr 1,2,4,8
-        BEM_SCAN_STEP(0x142, 0xa) BEM_SCAN_STEP(0x143, 0xc)                                                       // row_bcast 15 / 31
-        Pe = dpp_mov<0x138, 0xf>(1.f, P);   // wave_shr 1
-        Se = dpp_mov<0x138, 0xf>(0.f, S);
-    } else {
-        BEM_SCAN_STEP(0x101, 0xf) BEM_SCAN_STEP(0x102, 0xf) BEM_SCAN_STEP(0x104, 0xf) BEM_SCAN_STEP(0x108, 0xf)   // row_shl 1,2,4,8
-        const int lane = threadIdx.x & 63;
-        {   // rows 0 / 2 append the suffix of rows 1 / 3 (their lane 16 / 48)
-            const float P16 = lane_bcast(P, 16), S16 = lane_bcast(S, 16), P48 = lane_bcast(P, 48), S48 = lane_bcast(S, 48);
-            const bool take = (lane & 16) == 0;
-            const float Pp = take ? ((lane & 32) ? P48 : P16) : 1.f, Sp = take ? ((lane & 32) ? S48 : S16) : 0.f;
-            S = fmaf(P, Sp, S);
-            P = P * Pp;
-        }
-        {   // rows 0, 1 append the suffix of rows 2, 3 (lane 32)
-            const float P32 = lane_bcast(P, 32), S32 = lane_bcast(S, 32);
-            const bool take = lane < 32;
-            const float Pp = take ? P32 : 1.f, Sp = take ? S32 : 0.f;
-            S = fmaf(P, Sp, S);
-            P = P * Pp;
-        }
-        Pe = dpp_mov<0x130, 0xf>(1.f, P);   // wave_shl 1
-        Se = dpp_mov<0x130, 0xf>(0.f, S);
-    }
-}
-#undef BEM_SCAN_STEP
 
 // TR: orientation 1 works on the ROW-MAJOR planes too (x1 = x0's tensor, y1 written row-major): a workgroup of that
 // orientation stages its CB planes in LDS (row pitch W + 1), reads its column-major scan positions from there and sends

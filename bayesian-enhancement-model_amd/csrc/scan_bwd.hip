@@ -15,6 +15,7 @@
 //             dA += sum dh dt a h_prev, dD += sum dy x, ddtb += sum ddt, ddtw[r] += sum ddt xd[r]   (block sums, one atomic each)
 // dA is returned as the gradient of A_logs (A = -exp(A_logs): dA_logs = dA * A).
 #include "scan_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -206,6 +207,258 @@ __global__ __launch_bounds__(NT) void ss2d_scan_bwd_kernel(
                               dDs + kr * C + c, ddtb + kr * C + c, ddtw + ((int64_t)kr * C + c) * R);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Whole-row, channel-blocked form for L == NT * 4 * T (the planes of 256x256 / 128x128 inputs): the structure of the forward's
+// ss2d_scan_rows_kernel.  A workgroup owns CB channels of one (orientation, image); tiles are the outer loop, channels the
+// inner one, so the float4 of every x_dbl plane is loaded once per tile and the x_dbl gradient of a tile is summed over the CB
+// channels in registers before it is added to memory (CB times fewer atomics, and each atomic wave-instruction covers 256
+// contiguous bytes after a wave-private LDS transpose: the full-rate shape).
+//   pass 1 (tiles in scan order)   state entering every thread's 4 elements, kept in registers (CB x T floats)
+//   pass 2 (tiles in reverse)      replay h from it, then the adjoint recurrence in the form g_t = a_t (C_t dy_t + g_{t+1}),
+//                                  dh_t = C_t dy_t + g_{t+1}: its per-thread map needs only the thread's own a's, so the DPP
+//                                  wavefront scan + one LDS barrier per (tile, channel) is all the communication there is.
+// ------------------------------------------------------------------------------------------------------------------------
+template <int NT, int T, int CB, int R>
+__global__ __launch_bounds__(NT) void ss2d_scan_bwd_rows_kernel(
+    const float* x0, const float* x1, const float* xd0, const float* xd1, const float* dy0, const float* dy1,
+    const float* __restrict__ dtw, const float* __restrict__ dtb, const float* __restrict__ A, const float* __restrict__ Ds,
+    float* dx0, float* dx1, float* dxd0, float* dxd1, float* __restrict__ dAlog, float* __restrict__ dDs, float* __restrict__ ddtw,
+    float* __restrict__ ddtb, int Bn, int C, int64_t xbs0, int64_t xbs1) {
+    constexpr int NW = NT / BEM_WAVE, L = NT * 4 * T, NP = 3 + R;
+    __shared__ float agg[2][2 * NW];
+    __shared__ float tbuf[NT * 4];
+    __shared__ float redp[NW][CB * NP];
+    extern __shared__ float enter_sm[];                 // [CB][T][NT]: state entering every thread's 4 elements of every tile
+    const int G = (C + CB - 1) / CB;
+    const int total = gridDim.x, lin = blockIdx.x;
+    const int per = total / 8, rem = total % 8, xcd = lin % 8, idx = lin / 8;
+    const int wi = xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
+    const int g = wi % G, b = (wi / G) % Bn, o = wi / (G * Bn);
+    const float* xb = (o ? x1 : x0) + (int64_t)b * C * L;
+    const float* dyb = (o ? dy1 : dy0) + (int64_t)b * C * L;
+    float* dxb = (o ? dx1 : dx0) + (int64_t)b * C * L;
+    const float* xdb = o ? xd1 + (int64_t)b * xbs1 : xd0 + (int64_t)b * xbs0;
+    float* dxdb = (o ? dxd1 : dxd0) + (int64_t)b * 2 * (R + 2) * L;
+    const int lane = threadIdx.x & (BEM_WAVE - 1), wave = threadIdx.x / BEM_WAVE;
+    int slot = 0;
+    constexpr float LOG2E = 1.44269504088896340736f, LN2 = 0.69314718055994530942f;
+#pragma unroll
+    for (int dir = 0; dir < 2; ++dir) {
+        const float* xd = xdb + (int64_t)dir * (R + 2) * L;
+        float* dxd = dxdb + (int64_t)dir * (R + 2) * L;
+        const int kd = o + 2 * dir;
+        float carry[CB];
+#pragma unroll
+        for (int ch = 0; ch < CB; ++ch) carry[ch] = 0.f;
+        // ---------------- pass 1 ----------------
+#pragma unroll 1
+        for (int kk = 0; kk < T; ++kk) {
+            const int k = dir ? T - 1 - kk : kk;
+            const int pos = (k * NT + threadIdx.x) * 4;
+            __builtin_amdgcn_sched_barrier(0);
+            float4 dq[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) dq[r] = *reinterpret_cast<const float4*>(xd + (int64_t)r * L + pos);
+            const float4 Bq = *reinterpret_cast<const float4*>(xd + (int64_t)R * L + pos);
+            const float Bv[4] = {Bq.x, Bq.y, Bq.z, Bq.w};
+#pragma unroll
+            for (int ch = 0; ch < CB; ++ch) {
+                const int c = min(g * CB + ch, C - 1);
+                __builtin_amdgcn_sched_barrier(0);
+                const float4 xq = *reinterpret_cast<const float4*>(xb + (int64_t)c * L + pos);
+                const float xv[4] = {xq.x, xq.y, xq.z, xq.w};
+                const float* wd = dtw + ((int64_t)kd * C + c) * R;
+                const float bias = dtb[kd * C + c], Ak = A[kd * C + c];
+                float z[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) z[e] = bias;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float w = wd[r];
+                    z[0] = fmaf(w, dq[r].x, z[0]); z[1] = fmaf(w, dq[r].y, z[1]);
+                    z[2] = fmaf(w, dq[r].z, z[2]); z[3] = fmaf(w, dq[r].w, z[3]);
+                }
+                float P = 1.f, S = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = dir ? 3 - i : i;
+                    const float lg = z[e] <= 20.f ? __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(z[e] * LOG2E)) : z[e] * LOG2E;
+                    const float a = __builtin_amdgcn_exp2f(lg * Ak);
+                    S = fmaf(a, S, lg * LN2 * Bv[e] * xv[e]);
+                    P = P * a;
+                }
+                float Pe, Se;
+                if (dir) wave_scan_affine<true>(P, S, Pe, Se);
+                else wave_scan_affine<false>(P, S, Pe, Se);
+                const float hw = dir ? cross_wave_affine<NW, true>(P, S, agg[slot], carry[ch]) : cross_wave_affine<NW, false>(P, S, agg[slot], carry[ch]);
+                slot ^= 1;
+                enter_sm[(ch * T + k) * NT + threadIdx.x] = fmaf(Pe, hw, Se);
+            }
+        }
+        // ---------------- pass 2 ----------------
+        float rq[CB], pacc[CB][NP];
+#pragma unroll
+        for (int ch = 0; ch < CB; ++ch) {
+            rq[ch] = 0.f;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) pacc[ch][q] = 0.f;
+        }
+#pragma unroll 1
+        for (int kk = T - 1; kk >= 0; --kk) {
+            const int k = dir ? T - 1 - kk : kk;
+            const int pos = (k * NT + threadIdx.x) * 4;
+            __builtin_amdgcn_sched_barrier(0);
+            float4 dq[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) dq[r] = *reinterpret_cast<const float4*>(xd + (int64_t)r * L + pos);
+            const float4 Bq = *reinterpret_cast<const float4*>(xd + (int64_t)R * L + pos);
+            const float4 Cq = *reinterpret_cast<const float4*>(xd + (int64_t)(R + 1) * L + pos);
+            const float Bv[4] = {Bq.x, Bq.y, Bq.z, Bq.w}, Cv[4] = {Cq.x, Cq.y, Cq.z, Cq.w};
+            float acc[R + 2][4];
+#pragma unroll
+            for (int q = 0; q < R + 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[q][e] = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < CB; ++ch) {
+                const int c = min(g * CB + ch, C - 1);
+                const bool live = g * CB + ch < C;              // a partial last group recomputes channel C - 1 without contributing
+                __builtin_amdgcn_sched_barrier(0);
+                const float4 xq = *reinterpret_cast<const float4*>(xb + (int64_t)c * L + pos);
+                const float4 gq = *reinterpret_cast<const float4*>(dyb + (int64_t)c * L + pos);
+                const float xv[4] = {xq.x, xq.y, xq.z, xq.w}, dy[4] = {gq.x, gq.y, gq.z, gq.w};
+                const float* wd = dtw + ((int64_t)kd * C + c) * R;
+                const float bias = dtb[kd * C + c], Ak = A[kd * C + c], Dk = Ds[kd * C + c];
+                float wr[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) wr[r] = wd[r];
+                float z[4], lg[4], a[4], bb[4], h[4], br[4], dh[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) z[e] = bias;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    z[0] = fmaf(wr[r], dq[r].x, z[0]); z[1] = fmaf(wr[r], dq[r].y, z[1]);
+                    z[2] = fmaf(wr[r], dq[r].z, z[2]); z[3] = fmaf(wr[r], dq[r].w, z[3]);
+                }
+                float hh = enter_sm[(ch * T + k) * NT + threadIdx.x];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = dir ? 3 - i : i;
+                    lg[e] = z[e] <= 20.f ? __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(z[e] * LOG2E)) : z[e] * LOG2E;
+                    a[e] = __builtin_amdgcn_exp2f(lg[e] * Ak);
+                    bb[e] = lg[e] * LN2 * Bv[e] * xv[e];
+                    hh = fmaf(a[e], hh, bb[e]);
+                    h[e] = hh;
+                    br[e] = Cv[e] * dy[e];
+                }
+                // adjoint: visit the elements in reverse scan order, g' = a_e (br_e + g)
+                float P = 1.f, S = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = dir ? i : 3 - i;
+                    S = a[e] * (S + br[e]);
+                    P = P * a[e];
+                }
+                float Pe, Se;
+                if (dir) wave_scan_affine<false>(P, S, Pe, Se);
+                else wave_scan_affine<true>(P, S, Pe, Se);
+                const float qw = dir ? cross_wave_affine<NW, false>(P, S, agg[slot], rq[ch]) : cross_wave_affine<NW, true>(P, S, agg[slot], rq[ch]);
+                slot ^= 1;
+                float gg = fmaf(Pe, qw, Se);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = dir ? i : 3 - i;
+                    dh[e] = br[e] + gg;
+                    gg = a[e] * dh[e];
+                }
+                const float lv = live ? 1.f : 0.f;
+                float dxv[4], dz[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float dl = lg[e] * LN2;
+                    const float hm = h[e] - bb[e];
+                    const float dhd = dh[e] * dl * lv;
+                    dxv[e] = fmaf(dhd, Bv[e], Dk * dy[e]);
+                    const float ddl = dh[e] * fmaf(Bv[e], xv[e], Ak * hm);
+                    const float sg = z[e] <= 20.f ? 1.f - __builtin_amdgcn_exp2f(-lg[e]) : 1.f;      // sigmoid(z) = 1 - 2^-log2(1 + e^z)
+                    dz[e] = ddl * sg * lv;
+                    acc[R][e] = fmaf(dhd, xv[e], acc[R][e]);
+                    acc[R + 1][e] = fmaf(dy[e] * lv, h[e], acc[R + 1][e]);
+                    pacc[ch][0] = fmaf(dhd, hm, pacc[ch][0]);
+                    pacc[ch][1] = fmaf(dy[e], xv[e], pacc[ch][1]);
+                    pacc[ch][2] += dz[e];
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    acc[r][0] = fmaf(dz[0], wr[r], acc[r][0]); acc[r][1] = fmaf(dz[1], wr[r], acc[r][1]);
+                    acc[r][2] = fmaf(dz[2], wr[r], acc[r][2]); acc[r][3] = fmaf(dz[3], wr[r], acc[r][3]);
+                    pacc[ch][3 + r] += fmaf(dz[0], dq[r].x, fmaf(dz[1], dq[r].y, fmaf(dz[2], dq[r].z, dz[3] * dq[r].w)));
+                }
+                if (live) {
+                    float* dp = dxb + (int64_t)c * L + pos;
+                    if (dir) {
+                        const float4 pv = *reinterpret_cast<const float4*>(dp);
+                        dxv[0] += pv.x; dxv[1] += pv.y; dxv[2] += pv.z; dxv[3] += pv.w;
+                    }
+                    *reinterpret_cast<float4*>(dp) = make_float4(dxv[0], dxv[1], dxv[2], dxv[3]);
+                }
+            }
+            // tile flush: wave-private LDS transpose, then four 256-byte-contiguous atomic wave-instructions per plane
+            float* tw = tbuf + wave * 256;
+            float* dbase = dxd + (int64_t)(k * NT + wave * BEM_WAVE) * 4;
+#pragma unroll
+            for (int q = 0; q < R + 2; ++q) {
+                *reinterpret_cast<float4*>(tw + lane * 4) = make_float4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) atomicAdd(dbase + (int64_t)q * L + 64 * j + lane, tw[64 * j + lane]);
+            }
+        }
+        // parameter gradients of this direction: wave sums -> LDS -> one atomic per value
+#pragma unroll
+        for (int ch = 0; ch < CB; ++ch)
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                float v = pacc[ch][q];
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, BEM_WAVE);
+                if (lane == 0) redp[wave][ch * NP + q] = v;
+            }
+        __syncthreads();
+        if (threadIdx.x < CB * NP) {
+            const int ch = threadIdx.x / NP, q = threadIdx.x % NP, c = g * CB + ch;
+            if (c < C) {
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) v += redp[w][threadIdx.x];
+                const int kc = kd * C + c;
+                if (q == 0) atomicAdd(dAlog + kc, v * A[kc]);
+                else if (q == 1) atomicAdd(dDs + kc, v);
+                else if (q == 2) atomicAdd(ddtb + kc, v);
+                else atomicAdd(ddtw + (int64_t)kc * R + (q - 3), v);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int NT, int T, int CB, int R>
+static int launch_bwd_rows(const float* x0, const float* x1, const float* xd0, const float* xd1, const float* dy0, const float* dy1, const float* dtw,
+                           const float* dtb, const float* A, const float* Ds, float* dx0, float* dx1, float* dxd0, float* dxd1, float* dAlog, float* dDs,
+                           float* ddtw, float* ddtb, int B, int C, int64_t xbs0, int64_t xbs1, hipStream_t s) {
+    const int G = (C + CB - 1) / CB;
+    constexpr size_t lds = sizeof(float) * CB * T * NT;
+    static_assert(lds + sizeof(float) * (NT * 4 + 64 + (NT / 64) * CB * (3 + R)) <= 160 * 1024, "LDS budget");
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ss2d_scan_bwd_rows_kernel<NT, T, CB, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    ss2d_scan_bwd_rows_kernel<NT, T, CB, R><<<G * B * 2, NT, lds, s>>>(x0, x1, xd0, xd1, dy0, dy1, dtw, dtb, A, Ds, dx0, dx1, dxd0, dxd1, dAlog, dDs,
+                                                                      ddtw, ddtb, B, C, xbs0, xbs1);
+    return bem_check_launch("ss2d_scan_bwd(rows)");
+}
+
 }  // namespace
 
 // x0, x1, dy0, dy1, dx0, dx1: (B,C,L) (orientation 0 row-major pixel order, orientation 1 transposed order); xd0, xd1 as in
@@ -228,6 +481,20 @@ extern "C" int bem_ss2d_scan_bwd_f32(const float* x0, const float* x1, const flo
     hipStream_t s = (hipStream_t)stream;
     const size_t nd = sizeof(float) * (size_t)B * 2 * (R + 2) * L;
     if (hipMemsetAsync(dxd0, 0, nd, s) != hipSuccess || hipMemsetAsync(dxd1, 0, nd, s) != hipSuccess) return bem_check_launch("ss2d_scan_bwd memset");
+    static const bool fast = !(getenv("BEM_SCAN_BWD_ROWS") && atoi(getenv("BEM_SCAN_BWD_ROWS")) == 0);
+    if (fast) {
+        // whole-row channel-blocked forms for the plane sizes / dt_ranks of the shipped configuration (n_feat 40: R = 3 / 5 / 10)
+#define BEM_BWD_ROWS(NT, T, CB, RR) return launch_bwd_rows<NT, T, CB, RR>(x0, x1, xd0, xd1, dy0, dy1, dtw, dtb, A, Ds, dx0, dx1, dxd0, dxd1, dAlog, dDs, ddtw, ddtb, B, C, xbs0, xbs1, s)
+        if (L == 16384 && R == 3) BEM_BWD_ROWS(512, 8, 4, 3);
+        if (L == 4096 && R == 3) BEM_BWD_ROWS(256, 4, 4, 3);
+        if (L == 4096 && R == 5) BEM_BWD_ROWS(256, 4, 4, 5);
+        if (L == 1024 && R == 5) BEM_BWD_ROWS(256, 1, 4, 5);
+        if (L == 1024 && R == 10) BEM_BWD_ROWS(256, 1, 2, 10);
+        if (L == 256 && R == 10) BEM_BWD_ROWS(64, 1, 2, 10);
+        if (L == 1024 && R == 1) BEM_BWD_ROWS(256, 1, 4, 1);
+        if (L == 1024 && R == 2) BEM_BWD_ROWS(256, 1, 2, 2);
+#undef BEM_BWD_ROWS
+    }
     const int grid = C * B * 2;
     if (L <= 1024)
         ss2d_scan_bwd_kernel<256, 4><<<grid, 256, 0, s>>>(x0, x1, xd0, xd1, dy0, dy1, dtw, dtb, A, Ds, dx0, dx1, dxd0, dxd1, dAlog, dDs, ddtw, ddtb, B, C, L, R, xbs0, xbs1);

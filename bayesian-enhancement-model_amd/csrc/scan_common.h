@@ -118,4 +118,88 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* sh) {
     return s;
 }
 
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_mov(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                                 CTRL, ROWMASK, 0xf, false));
+}
+__device__ __forceinline__ float lane_bcast(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+#define BEM_SCAN_STEP(CTRL, RM)                                         \
+    {                                                                   \
+        const float Pp = dpp_mov<CTRL, RM>(1.f, P), Sp = dpp_mov<CTRL, RM>(0.f, S); \
+        S = fmaf(P, Sp, S);                                             \
+        P = P * Pp;                                                     \
+    }
+// inclusive scan of the per-lane affine maps (P, S) in ascending (REV = false) / descending (REV = true) lane order;
+// returns the exclusive map (Pe, Se) of every lane and leaves the wavefront total in lane 63 (0 for REV).
+template <bool REV>
+__device__ __forceinline__ void wave_scan_affine(float& P, float& S, float& Pe, float& Se) {
+    if (!REV) {
+        BEM_SCAN_STEP(0x111, 0xf) BEM_SCAN_STEP(0x112, 0xf) BEM_SCAN_STEP(0x114, 0xf) BEM_SCAN_STEP(0x118, 0xf)   // row_shr 1,2,4,8
+        BEM_SCAN_STEP(0x142, 0xa) BEM_SCAN_STEP(0x143, 0xc)                                                       // row_bcast 15 / 31
+        Pe = dpp_mov<0x138, 0xf>(1.f, P);   // wave_shr 1
+        Se = dpp_mov<0x138, 0xf>(0.f, S);
+    } else {
+        BEM_SCAN_STEP(0x101, 0xf) BEM_SCAN_STEP(0x102, 0xf) BEM_SCAN_STEP(0x104, 0xf) BEM_SCAN_STEP(0x108, 0xf)   // row_shl 1,2,4,8
+        const int lane = threadIdx.x & 63;
+        {   // rows 0 / 2 append the suffix of rows 1 / 3 (their lane 16 / 48)
+            const float P16 = lane_bcast(P, 16), S16 = lane_bcast(S, 16), P48 = lane_bcast(P, 48), S48 = lane_bcast(S, 48);
+            const bool take = (lane & 16) == 0;
+            const float Pp = take ? ((lane & 32) ? P48 : P16) : 1.f, Sp = take ? ((lane & 32) ? S48 : S16) : 0.f;
+            S = fmaf(P, Sp, S);
+            P = P * Pp;
+        }
+        {   // rows 0, 1 append the suffix of rows 2, 3 (lane 32)
+            const float P32 = lane_bcast(P, 32), S32 = lane_bcast(S, 32);
+            const bool take = lane < 32;
+            const float Pp = take ? P32 : 1.f, Sp = take ? S32 : 0.f;
+            S = fmaf(P, Sp, S);
+            P = P * Pp;
+        }
+        Pe = dpp_mov<0x130, 0xf>(1.f, P);   // wave_shl 1
+        Se = dpp_mov<0x130, 0xf>(0.f, S);
+    }
+}
+#undef BEM_SCAN_STEP
+
+// Cross-wave step of a block scan whose wavefront part ran on wave_scan_affine<REV>: (P, S) is the inclusive map of the lane,
+// i.e. the wavefront total sits in lane 63 (lane 0 for REV).  The NW totals go through the LDS slot `ag` (2 NW floats, ONE
+// barrier; the caller rotates slots so that a slot is rewritten only after later barriers) and are composed in scan order on
+// one 16-lane DPP row.  Returns the state entering this wavefront and advances `carry` (state entering the block) to the state
+// leaving it.
+template <int NW, bool REV>
+__device__ __forceinline__ float cross_wave_affine(float P, float S, float* ag, float& carry) {
+    static_assert(NW <= 16, "the cross-wave scan uses one DPP row");
+    const int lane = threadIdx.x & (BEM_WAVE - 1), wave = threadIdx.x / BEM_WAVE;
+    if (NW == 1) {
+        const float Pt = lane_bcast(P, REV ? 0 : BEM_WAVE - 1), St = lane_bcast(S, REV ? 0 : BEM_WAVE - 1);
+        const float hw = carry;
+        carry = fmaf(Pt, hw, St);
+        return hw;
+    }
+    if (lane == (REV ? 0 : BEM_WAVE - 1)) { ag[2 * wave] = P; ag[2 * wave + 1] = S; }
+    __syncthreads();
+    const int sl = min(lane, NW - 1), src = REV ? NW - 1 - sl : sl;
+    const float Pl = ag[2 * src], Sl = ag[2 * src + 1];
+    float Pw = lane < NW ? Pl : 1.f, Sw = lane < NW ? Sl : 0.f;
+#define BEM_ROW_STEP(CTRL)                                                             \
+    {                                                                                  \
+        const float Pp = dpp_mov<CTRL, 0xf>(1.f, Pw), Sp = dpp_mov<CTRL, 0xf>(0.f, Sw); \
+        Sw = fmaf(Pw, Sp, Sw);                                                         \
+        Pw = Pw * Pp;                                                                  \
+    }
+    BEM_ROW_STEP(0x111) BEM_ROW_STEP(0x112)
+    if (NW > 4) { BEM_ROW_STEP(0x114) }
+    if (NW > 8) { BEM_ROW_STEP(0x118) }
+#undef BEM_ROW_STEP
+    const int rw = REV ? NW - 1 - wave : wave;
+    const float Pt = lane_bcast(Pw, NW - 1), St = lane_bcast(Sw, NW - 1);
+    const float Px = lane_bcast(Pw, rw > 0 ? rw - 1 : 0), Sx = lane_bcast(Sw, rw > 0 ? rw - 1 : 0);
+    const float c0 = carry;
+    carry = fmaf(Pt, c0, St);
+    return rw > 0 ? fmaf(Px, c0, Sx) : c0;
+}
+
 }  // namespace

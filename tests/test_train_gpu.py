@@ -214,7 +214,9 @@ def _ss2d_torch(x0, x1, xd0, xd1, dtw, dtb, A, Ds):
     return ys
 
 
-@pytest.mark.parametrize("B,C,L,R", [(2, 8, 192, 3), (1, 5, 77, 2), (1, 4, 1030, 1), (1, 3, 4100, 3), (1, 2, 9000, 2)])
+@pytest.mark.parametrize("B,C,L,R", [(2, 8, 192, 3), (1, 5, 77, 2), (1, 4, 1030, 1), (1, 3, 4100, 3), (1, 2, 9000, 2),
+                                     # whole-row channel-blocked forms (full and partial channel groups)
+                                     (2, 5, 1024, 2), (1, 6, 1024, 1), (1, 5, 4096, 3), (1, 9, 1024, 5), (1, 3, 256, 10), (1, 5, 16384, 3)])
 def test_ss2d_scan_bwd(dev, B, C, L, R):
     from bem import ops
     g = G(8)
