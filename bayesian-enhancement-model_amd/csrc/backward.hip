@@ -200,6 +200,99 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     }
 }
 
+// Faster form for C <= 160: the four wavefronts of a workgroup split the channels of the same 64 pixels (CPT = ceil(C / 4) each),
+// x and dn are read ONCE into registers (all loads of a tile issue back to back), the per-pixel statistics are combined through
+// LDS (two barriers per tile), dgamma / dbeta accumulate in registers over the workgroup's tiles (one atomic per channel at the end).
+template <int CPT, int NWV>
+__global__ __launch_bounds__(64 * NWV) void ln_bwd_split_kernel(const float* __restrict__ x1, const float* __restrict__ x2, const float* __restrict__ dn,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                                const float* __restrict__ dres, float* __restrict__ dx, float* __restrict__ n_out,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, int C, int64_t L,
+                                                                int64_t tiles_per_img, int64_t total_tiles, int tiles_per_wg) {
+    __shared__ float red[4][NWV][64];
+    const int lane = threadIdx.x & 63;
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: channel indices, gamma / beta stay scalar
+    const int c0 = q * CPT;
+    const float invC = 1.f / (float)C;
+    float ag[CPT], ab[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) ag[j] = ab[j] = 0.f;
+    const int64_t t_end = min((int64_t)(blockIdx.x + 1) * tiles_per_wg, total_tiles);
+    for (int64_t t = (int64_t)blockIdx.x * tiles_per_wg; t < t_end; ++t) {
+        const int64_t b = t / tiles_per_img, tile = t - b * tiles_per_img;
+        const int64_t p = tile * 64 + lane;
+        const bool ok = p < L;
+        const int64_t base = b * C * L + (ok ? p : L - 1);
+        float xv[CPT], dv[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) xv[j] = x1[base + (int64_t)min(c0 + j, C - 1) * L];
+        if (x2) {
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) xv[j] += x2[base + (int64_t)min(c0 + j, C - 1) * L];
+        }
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) dv[j] = dn[base + (int64_t)min(c0 + j, C - 1) * L];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) s += (c0 + j < C) ? xv[j] : 0.f;
+        red[0][q][lane] = s;
+        __syncthreads();
+        float mu = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) mu += red[0][w][lane];
+        mu *= invC;
+        float var = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const bool live = c0 + j < C;
+            const float d = live ? xv[j] - mu : 0.f;
+            const float g = live ? dv[j] * gamma[min(c0 + j, C - 1)] : 0.f;
+            xv[j] = d;
+            var = fmaf(d, d, var);
+            s1 += g;
+            s2 = fmaf(g, d, s2);
+        }
+        red[1][q][lane] = var; red[2][q][lane] = s1; red[3][q][lane] = s2;
+        __syncthreads();
+        var = s1 = s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) { var += red[1][w][lane]; s1 += red[2][w][lane]; s2 += red[3][w][lane]; }
+        const float rstd = rsqrtf(var * invC + eps);
+        s1 *= invC;
+        s2 *= invC * rstd;
+        const float okm = ok ? 1.f : 0.f;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int c = min(c0 + j, C - 1);
+            const float gm = gamma[c];
+            const float xh = xv[j] * rstd;
+            float r = rstd * (dv[j] * gm - s1 - xh * s2);
+            const int64_t idx = base + (int64_t)c * L;
+            if (dres) r += dres[idx];
+            if (ok && c0 + j < C) {
+                dx[idx] = r;
+                if (n_out) n_out[idx] = fmaf(xh, gm, beta[c]);
+            }
+            ag[j] = fmaf(dv[j] * okm, xh, ag[j]);
+            ab[j] = fmaf(dv[j], okm, ab[j]);
+        }
+    }
+    // dgamma / dbeta of this workgroup: wave sums -> LDS (channel order) -> two contiguous atomic wave-instructions per 64 channels
+    // (single-lane atomics from thousands of wavefronts onto the same few addresses serialise at the memory side)
+    __syncthreads();
+    float* gsum = &red[0][0][0];                        // [2][NWV * CPT] <= 4 * NWV * 64 floats
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const float a = wave_sum(ag[j]), b2 = wave_sum(ab[j]);
+        if (lane == 0) { gsum[c0 + j] = a; gsum[NWV * CPT + c0 + j] = b2; }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 64 * NWV) {
+        atomicAdd(dgamma + c, gsum[c]);
+        atomicAdd(dbeta + c, gsum[NWV * CPT + c]);
+    }
+}
+
 // LayerNorm2d forward alone (the normalised tensor of a weight-gradient GEMM when no backward pass through the norm is needed)
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ x2, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps, float* __restrict__ n_out, int C, int64_t L,
@@ -456,10 +549,23 @@ extern "C" int bem_ln_bwd_f32(const float* x1, const float* x2, const float* dn,
                               const float* dres, float* dx, float* n_out, float* dgamma, float* dbeta, int B, int C, int64_t L, void* stream) {
     BEM_REQUIRE(x1 && dn && gamma && beta && dx && dgamma && dbeta, "ln_bwd: null pointer");
     BEM_REQUIRE(B > 0 && C > 0 && C <= 4096 && L > 0, "ln_bwd: bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    if (C <= 160) {
+        const int64_t tpi = cdiv64(L, 64), total = tpi * B;
+        const int tpw = (int)std::max<int64_t>(1, cdiv64(total, 1024));
+        const unsigned grid = (unsigned)cdiv64(total, tpw);
+#define BEM_LNB(CPT, NWV) ln_bwd_split_kernel<CPT, NWV><<<grid, 64 * NWV, 0, s>>>(x1, x2, dn, gamma, beta, eps, dres, dx, n_out, dgamma, dbeta, C, L, tpi, total, tpw)
+        if (C <= 16) BEM_LNB(4, 4);
+        else if (C <= 40) BEM_LNB(10, 4);
+        else if (C <= 80) BEM_LNB(10, 8);
+        else BEM_LNB(20, 8);
+#undef BEM_LNB
+        return bem_check_launch("ln_bwd");
+    }
     const int64_t tiles = cdiv64(L, 256);
     BEM_REQUIRE(tiles * B < (1ll << 31), "ln_bwd: grid too large");
-    ln_bwd_kernel<<<dim3((unsigned)(tiles * B)), 256, 2 * C * sizeof(float), (hipStream_t)stream>>>(x1, x2, dn, gamma, beta, eps, dres, dx, n_out,
-                                                                                                  dgamma, dbeta, C, L, tiles);
+    ln_bwd_kernel<<<dim3((unsigned)(tiles * B)), 256, 2 * C * sizeof(float), s>>>(x1, x2, dn, gamma, beta, eps, dres, dx, n_out,
+                                                                                 dgamma, dbeta, C, L, tiles);
     return bem_check_launch("ln_bwd");
 }
 

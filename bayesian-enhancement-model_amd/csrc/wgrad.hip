@@ -34,8 +34,8 @@ struct WgK {
 
 constexpr int PT = 32, LDR = 33;
 
-template <int MTW, int NTW>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgK k) {
+template <int MTW, int NTW, bool CONV, bool VEC>      // VEC: L % 4 == 0 (a compile-time variant: a runtime flag puts a branch next to every load)
+__global__ __launch_bounds__(256, (MTW * NTW >= 6 ? 1 : 2)) void wgrad_kernel(WgK k) {
     constexpr int MC = 128 * MTW, NC = 32 * NTW, NP = 4 * MTW + NTW;     // NP passes of 32 rows
     extern __shared__ float lds[];                                       // [(MC + NC)][LDR]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgK k) {
     const int m0 = blockIdx.y * MC, n0 = blockIdx.z * NC;
     const int c_begin = blockIdx.x * k.chunks_per_wg;
     const int c_end = min(c_begin + k.chunks_per_wg, k.total_chunks);
-    const bool vecA = (k.L & 3) == 0, vec = vecA && !k.conv;
+    constexpr bool vec = VEC;
     const int lrow = tid >> 3, lq = tid & 7;                             // staging role: row within a 32-row pass, float4 slot
 
     f32x16 acc[MTW][NTW];
@@ -57,67 +57,80 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgK k) {
 #pragma unroll
     for (int i = 0; i < MTW; ++i) rs[i] = 0.f;
 
+    // Addressing: one wave-uniform base pointer per operand and tile (SGPRs) + a 32-bit element offset per staging row; rows outside
+    // M / N read a clamped row and are multiplied by 0 when the tile is written to LDS (no branch next to a load: the NP loads
+    // of a tile issue back to back).  Per-row pointers held in registers spilled (14 x 64 bit on top of 96 accumulators).
+    // CONV: (ci, ky, kx) of this thread's gathered rows
+    int cci[NTW], cky[NTW], ckx[NTW];
+    if (CONV) {
+        const int T = k.KH * k.KW;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const int n = min(n0 + j * 32 + lrow, k.N - 1);
+            cci[j] = n / T;
+            const int tap = n - cci[j] * T;
+            cky[j] = tap / k.KW;
+            ckx[j] = tap - cky[j] * k.KW;
+        }
+    }
+
     float4 stage[NP];
     auto fetch = [&](int chunk) {
         const int b = chunk / k.tiles, tile = chunk - b * k.tiles;
         const int p = tile * PT + 4 * lq;
+        const int pc = vec ? min(p, k.L - 4) : 0;
+        const float* abase = k.a + (int64_t)b * k.a_bs;
+        const float* b1base = k.b1 + (int64_t)b * k.b1_bs;
+        const float* b2base = CONV ? b1base : k.b2 + (int64_t)b * k.b2_bs - (int64_t)k.C1 * k.L;   // indexed by the concatenated row
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int row = u * 32 + lrow;
-            if (u < 4 * MTW) {
-                const int m = m0 + row;
-                if (m < k.M) {
-                    const float* src = k.a + (int64_t)b * k.a_bs + (int64_t)m * k.L;
-                    if (vecA) { if (p < k.L) v = *reinterpret_cast<const float4*>(src + p); }
-                    else {
-                        if (p < k.L) v.x = src[p];
-                        if (p + 1 < k.L) v.y = src[p + 1];
-                        if (p + 2 < k.L) v.z = src[p + 2];
-                        if (p + 3 < k.L) v.w = src[p + 3];
-                    }
-                }
-            } else {
-                const int n = n0 + row - MC;
-                if (n < k.N) {
-                    if (!k.conv) {
-                        const float* src = n < k.C1 ? k.b1 + (int64_t)b * k.b1_bs + (int64_t)n * k.L
-                                                    : k.b2 + (int64_t)b * k.b2_bs + (int64_t)(n - k.C1) * k.L;
-                        if (vec) { if (p < k.L) v = *reinterpret_cast<const float4*>(src + p); }
-                        else {
-                            if (p < k.L) v.x = src[p];
-                            if (p + 1 < k.L) v.y = src[p + 1];
-                            if (p + 2 < k.L) v.z = src[p + 2];
-                            if (p + 3 < k.L) v.w = src[p + 3];
-                        }
-                    } else {
-                        const int T = k.KH * k.KW;
-                        const int ci = n / T, tap = n - ci * T, ky = tap / k.KW, kx = tap - ky * k.KW;
-                        const float* src = k.b1 + (int64_t)b * k.b1_bs + (int64_t)ci * k.Hin * k.Win;
-                        float e[4];
+            float4 v;
+            if (CONV && u >= 4 * MTW) {
+                const int j = u - 4 * MTW;
+                const float* src = b1base + (int64_t)cci[j] * k.Hin * k.Win;
+                float e[4];
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const int pp = p + t;
-                            const int oi = pp / k.Wout, oj = pp - oi * k.Wout;
-                            const int y = oi * k.S + ky - k.PAD, x = oj * k.S + kx - k.PAD;
-                            const bool ok = pp < k.L && y >= 0 && y < k.Hin && x >= 0 && x < k.Win;
-                            e[t] = ok ? src[(int64_t)y * k.Win + x] : 0.f;
-                        }
-                        v = make_float4(e[0], e[1], e[2], e[3]);
-                    }
+                for (int t = 0; t < 4; ++t) {
+                    const int pp = min(p + t, k.L - 1);
+                    const int oi = pp / k.Wout, oj = pp - oi * k.Wout;
+                    const int y = oi * k.S + cky[j] - k.PAD, x = oj * k.S + ckx[j] - k.PAD;
+                    const bool ok = y >= 0 && y < k.Hin && x >= 0 && x < k.Win;
+                    e[t] = src[min(max(y, 0), k.Hin - 1) * k.Win + min(max(x, 0), k.Win - 1)] * (ok ? 1.f : 0.f);
+                }
+                v = make_float4(e[0], e[1], e[2], e[3]);
+            } else {
+                const float* base;
+                unsigned off;
+                if (u < 4 * MTW) {
+                    base = abase;
+                    off = (unsigned)min(m0 + u * 32 + lrow, k.M - 1) * (unsigned)k.L;
+                } else {
+                    const int n = min(n0 + (u - 4 * MTW) * 32 + lrow, k.N - 1);
+                    base = n < k.C1 ? b1base : b2base;
+                    off = (unsigned)n * (unsigned)k.L;
+                }
+                if (vec) {
+                    v = *reinterpret_cast<const float4*>(base + off + pc);
+                } else {
+                    v = make_float4(base[off + min(p, k.L - 1)], base[off + min(p + 1, k.L - 1)], base[off + min(p + 2, k.L - 1)], base[off + min(p + 3, k.L - 1)]);
                 }
             }
-            stage[u] = v;
+            stage[u] = v;          // raw: the masks are applied when the tile is written to LDS, so nothing here waits for the loads
         }
     };
 
     if (c_begin < c_end) fetch(c_begin);
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
         __syncthreads();                       // the previous tile's operand reads are done
+        {
+            const int p = (chunk % k.tiles) * PT + 4 * lq;
+            const float m0v = p < k.L ? 1.f : 0.f, m1v = p + 1 < k.L ? 1.f : 0.f, m2v = p + 2 < k.L ? 1.f : 0.f, m3v = p + 3 < k.L ? 1.f : 0.f;
 #pragma unroll
-        for (int u = 0; u < NP; ++u) {
-            float* d = lds + (u * 32 + lrow) * LDR + 4 * lq;
-            d[0] = stage[u].x; d[1] = stage[u].y; d[2] = stage[u].z; d[3] = stage[u].w;
+            for (int u = 0; u < NP; ++u) {
+                float* d = lds + (u * 32 + lrow) * LDR + 4 * lq;
+                const float rm = (u < 4 * MTW ? m0 + u * 32 + lrow < k.M : n0 + (u - 4 * MTW) * 32 + lrow < k.N) ? 1.f : 0.f;
+                d[0] = stage[u].x * (rm * m0v); d[1] = stage[u].y * (rm * m1v); d[2] = stage[u].z * (rm * m2v); d[3] = stage[u].w * (rm * m3v);
+            }
         }
         __syncthreads();
         if (chunk + 1 < c_end) fetch(chunk + 1);
@@ -162,22 +175,29 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgK k) {
     }
 }
 
-template <int MTW, int NTW>
-int launch_wgrad(WgK k, hipStream_t s) {
+template <int MTW, int NTW, bool CONV, bool VEC>
+int launch_wgrad_t(WgK k, hipStream_t s) {
     constexpr int MC = 128 * MTW, NC = 32 * NTW;
     const int ny = cdiv(k.M, MC), nz = cdiv(k.N, NC);
     k.tiles = cdiv(k.L, PT);
     k.total_chunks = k.B * k.tiles;
-    const int target = std::max(1, 2048 / (ny * nz));
+    // every pixel split ends in MC x NC float atomics onto the same dW block: few, long splits (about two workgroups per CU)
+    const int target = std::max(1, 512 / (ny * nz));
     k.chunks_per_wg = std::max(8, cdiv(k.total_chunks, target));
     const int nx = cdiv(k.total_chunks, k.chunks_per_wg);
     const size_t shm = (size_t)(MC + NC) * LDR * sizeof(float);
     static_assert((MC + NC) * LDR * sizeof(float) <= 64 * 1024, "dynamic LDS above 64 KiB needs hipFuncSetAttribute");
-    wgrad_kernel<MTW, NTW><<<dim3(nx, ny, nz), 256, shm, s>>>(k);
+    wgrad_kernel<MTW, NTW, CONV, VEC><<<dim3(nx, ny, nz), 256, shm, s>>>(k);
     return bem_check_launch("wgrad");
+}
+template <int MTW, int NTW>
+int launch_wgrad(const WgK& k, hipStream_t s) {
+    return k.conv ? launch_wgrad_t<MTW, NTW, true, true>(k, s) : launch_wgrad_t<MTW, NTW, false, true>(k, s);
 }
 
 int dispatch_wgrad(const WgK& k, hipStream_t s) {
+    if (k.L & 3)          // ragged planes (tests, odd crops): one scalar-load variant
+        return k.conv ? launch_wgrad_t<1, 2, true, false>(k, s) : launch_wgrad_t<1, 2, false, false>(k, s);
     const int mt = cdiv(k.M, 32), nt = cdiv(k.N, 32);
     const int ntw = nt >= 4 ? 5 : nt;                       // 1, 2, 3 or 5 N-tiles per workgroup
     int mtw = ntw == 5 ? 1 : (ntw == 3 ? 2 : 3);            // MTW * NTW <= 6 accumulator tiles per wave
