@@ -44,6 +44,14 @@ struct PwX {
 };
 
 __device__ __forceinline__ uint32_t fbits(float v) { return __builtin_bit_cast(uint32_t, v); }
+// A real v_mov_b32: values that came back from LDS are copied once before packed-f32 arithmetic may pair them up.  On gfx950 a
+// v_pk_*_f32 working in place on an LDS-returned register pair through op_sel read the pair's pre-load content in lanes 48..63
+// a few times per 10^7 outputs (two workgroups per CU; waits correct) -- DESIGN.md section 6.4, scripts/isa_audit.py check 2.
+__device__ __forceinline__ float valu_copy(float v) {
+    float r;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
 __device__ __forceinline__ float bitsf(uint32_t u) { return __builtin_bit_cast(float, u); }
 
 // Workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2).  Give every XCD a contiguous run of pixel
@@ -197,7 +205,7 @@ __device__ __forceinline__ void x6_epilogue_generic(const PwX& k, int b, int mt0
 // is `global_store v_off, v_data, s[base]`; the 16 bias values of an M-tile come as four LDS float4 reads.  PReLU and
 // the residual are compile-time variants (chosen by uniform branches in x6_epilogue): without them a value costs one add.
 template <int MTW, int NSUB, bool VEC, bool ACT, bool RES>
-__device__ __forceinline__ void x6_epilogue_rows(const PwX& k, int b, int mt0, int p, const bool (&keep)[NSUB], int kh,
+__device__ __forceinline__ void x6_epilogue_rows(const PwX& k, int b, int mt0, int p, const bool (&keep)[NSUB], int kh, const float* s_bias,
                                                  const float4 (&bq)[MTW][4], const f32x16 (&acc)[MTW][NSUB]) {
     const float slope = ACT ? k.prelu[0] : 0.f;
     const int pv = VEC ? (keep[0] ? p : 0) : min(p, k.L - 1);
@@ -210,7 +218,22 @@ __device__ __forceinline__ void x6_epilogue_rows(const PwX& k, int b, int mt0, i
         const int rb = (mt0 + m) * 32;                        // uniform
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+#ifdef BEM_X6_BIAS_LDS      // A/B diagnostic builds only (make dbg, scripts/x6_bias_ab.py): bias read back from LDS
+#if BEM_X6_BIAS_LDS == 2      // 2: four separate dword reads, all retired (lgkmcnt(0)) before the first use
+            const float* sb = s_bias + rb + 8 * g + 4 * kh;
+            const float4 b4 = make_float4(sb[0], sb[1], sb[2], sb[3]);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+#elif BEM_X6_BIAS_LDS >= 3    // 3: one 16-byte read retired before the first use (the builtin keeps the compiler from sinking components); 4: + scalar adds
+            const float4 b4 = *reinterpret_cast<const float4*>(s_bias + rb + 8 * g + 4 * kh);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+#else                         // 1: the round-1 form: the compiler sinks the components into the conditional row blocks as
+                              //    ds_read2_b32 + 2 x ds_read_b32 and waits for them with COUNTED lgkmcnt(1) / lgkmcnt(0)
+            const float4 b4 = *reinterpret_cast<const float4*>(s_bias + rb + 8 * g + 4 * kh);
+#endif
+            const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#else
             const float bv[4] = {bq[m][g].x, bq[m][g].y, bq[m][g].z, bq[m][g].w};
+#endif
             float rv[4][NSUB];
             if (RES) {
 #pragma unroll
@@ -235,6 +258,9 @@ __device__ __forceinline__ void x6_epilogue_rows(const PwX& k, int b, int mt0, i
 #pragma unroll
                 for (int t = 0; t < NSUB; ++t) {
                     o[t] = acc[m][t][r] + bv[i];
+#if defined(BEM_X6_BIAS_LDS) && BEM_X6_BIAS_LDS == 4    // diagnostic: keep the two adds of a row scalar (no v_pk_add_f32)
+                    asm volatile("" : "+v"(o[t]));
+#endif
                     if (ACT) o[t] = o[t] >= 0.f ? o[t] : slope * o[t];
                     if (RES) o[t] += rv[i][t];
                 }
@@ -286,10 +312,10 @@ __device__ __forceinline__ void x6_epilogue(const PwX& k, int b, int mt0, int p,
                                             const float* __restrict__ s_bias, const float4 (&bq)[MTW][4], const f32x16 (&acc)[MTW][NSUB]) {
     if (k.out_mode != 0 || k.M < 8) { x6_epilogue_generic<MTW, NSUB, VEC>(k, b, mt0, p, keep, kh, s_bias, acc); return; }
     const bool act = k.act == 1, res = k.res != nullptr;      // uniform
-    if (!act && !res) x6_epilogue_rows<MTW, NSUB, VEC, false, false>(k, b, mt0, p, keep, kh, bq, acc);
-    else if (!act) x6_epilogue_rows<MTW, NSUB, VEC, false, true>(k, b, mt0, p, keep, kh, bq, acc);
-    else if (!res) x6_epilogue_rows<MTW, NSUB, VEC, true, false>(k, b, mt0, p, keep, kh, bq, acc);
-    else x6_epilogue_rows<MTW, NSUB, VEC, true, true>(k, b, mt0, p, keep, kh, bq, acc);
+    if (!act && !res) x6_epilogue_rows<MTW, NSUB, VEC, false, false>(k, b, mt0, p, keep, kh, s_bias, bq, acc);
+    else if (!act) x6_epilogue_rows<MTW, NSUB, VEC, false, true>(k, b, mt0, p, keep, kh, s_bias, bq, acc);
+    else if (!res) x6_epilogue_rows<MTW, NSUB, VEC, true, false>(k, b, mt0, p, keep, kh, s_bias, bq, acc);
+    else x6_epilogue_rows<MTW, NSUB, VEC, true, true>(k, b, mt0, p, keep, kh, s_bias, bq, acc);
 }
 
 // bias of this batch row -> LDS (zeros without a bias); M <= BEM_X6_MAXM
@@ -355,7 +381,8 @@ __global__ __launch_bounds__(256, 2) void pw_x6_res_kernel(PwX k) {
         for (int kb = 0; kb < KBM; ++kb)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float g = s_ln[16 * kb + 8 * kh + e], be = s_ln[16 * KBM + 16 * kb + 8 * kh + e];   // 0 on padded channels
+                // through a VALU copy: packed-f32 ops must not consume LDS-returned register pairs directly
+                const float g = valu_copy(s_ln[16 * kb + 8 * kh + e]), be = valu_copy(s_ln[16 * KBM + 16 * kb + 8 * kh + e]);   // 0 on padded channels
 #pragma unroll
                 for (int t = 0; t < NSUB; ++t) xr[kb][e][t] = (xr[kb][e][t] - mean[t]) * rstd[t] * g + be;
             }
@@ -522,7 +549,7 @@ __global__ __launch_bounds__(256, 2) void pw_x6_stream_kernel(PwX k) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 v[e] = xn[e][t];
-                if (LN) v[e] = (v[e] - mean[t]) * rstd[t] * s_ln[16 * kb + 8 * kh + e] + s_ln[BEM_X6_MAXK_LN + 16 * kb + 8 * kh + e];
+                if (LN) v[e] = (v[e] - mean[t]) * rstd[t] * valu_copy(s_ln[16 * kb + 8 * kh + e]) + valu_copy(s_ln[BEM_X6_MAXK_LN + 16 * kb + 8 * kh + e]);
             }
             split8(v, xl[t][0], xl[t][1], xl[t][2]);
         }

@@ -413,7 +413,7 @@ __global__ __launch_bounds__(NT) void ss2d_scan_full_kernel(
 // TR: orientation 1 works on the ROW-MAJOR planes too (x1 = x0's tensor, y1 written row-major): a workgroup of that
 // orientation stages its CB planes in LDS (row pitch W + 1), reads its column-major scan positions from there and sends
 // its result back through the same buffer, so neither the transposed copy of x nor the transposed y exist in HBM.
-template <int NT, int T, int CB, int R, int MINW, bool TR>
+template <int NT, int T, int CB, int R, int MINW, bool TR, int ORI = -1>
 __global__ __launch_bounds__(NT, MINW) void ss2d_scan_rows_kernel(
     // x / x_dbl deliberately not __restrict__: their loads must stay behind the barrier of the channel step they belong
     // to (as invariant loads the compiler hoists all CB * T * 2 steps' loads to the top and runs out of registers)
@@ -428,12 +428,12 @@ __global__ __launch_bounds__(NT, MINW) void ss2d_scan_rows_kernel(
     const int total = gridDim.x, lin = blockIdx.x;      // XCD-aware order: the channel groups of one (o, b) share an L2
     const int per = total / 8, rem = total % 8, xcd = lin % 8, idx = lin / 8;
     const int wi = xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
-    const int g = wi % G, b = (wi / G) % Bn, o = wi / (G * Bn);
+    const int g = wi % G, b = (wi / G) % Bn, o = ORI < 0 ? wi / (G * Bn) : ORI;
     const float* xb = (o ? x1 : x0) + (int64_t)b * C * L;
     const float* xdb = (o ? xd1 + (int64_t)b * xbs1 : xd0 + (int64_t)b * xbs0);
     float* yb = (o ? y1 : y0) + (int64_t)b * C * L;
     const int lane = threadIdx.x & (BEM_WAVE - 1), wave = threadIdx.x / BEM_WAVE;
-    const bool via_lds = TR && o == 1;                   // uniform per workgroup
+    const bool via_lds = TR && o == 1;                   // uniform per workgroup (a compile-time constant when ORI >= 0)
     // LDS plane layout: element (row, col) at (row >> 2) * (4 pitch + 1) + (row & 3) * pitch + col, pitch = W + 1.  A lane reads
     // 4 consecutive rows of one column (rows 4n .. 4n + 3): the extra +1 per group of 4 rows makes the lane stride
     // 4 pitch + 1 (odd), so the 32 lanes of a half-wave hit 32 different banks.
@@ -470,8 +470,13 @@ __global__ __launch_bounds__(NT, MINW) void ss2d_scan_rows_kernel(
 #pragma unroll
             for (int r = 0; r < R; ++r) dq[r] = *reinterpret_cast<const float4*>(xd + (int64_t)r * L + pos);
             const float4 Bq = *reinterpret_cast<const float4*>(xd + (int64_t)R * L + pos);
-            const float4 Cq = *reinterpret_cast<const float4*>(xd + (int64_t)(R + 1) * L + pos);
-            const float Bv[4] = {Bq.x, Bq.y, Bq.z, Bq.w}, Cv[4] = {Cq.x, Cq.y, Cq.z, Cq.w};
+            // orientation-1-only launch: C_t is loaded after the scan of a channel instead of being held across it (4 of the 64
+            // registers that form has; the plane is L2-resident)
+            constexpr bool LATE_C = TR && ORI == 1;
+            float4 Cq = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!LATE_C) Cq = *reinterpret_cast<const float4*>(xd + (int64_t)(R + 1) * L + pos);
+            const float Bv[4] = {Bq.x, Bq.y, Bq.z, Bq.w};
+            float Cv[4] = {Cq.x, Cq.y, Cq.z, Cq.w};
             // column-major scan position pos = col * H + row (H % 4 == 0: the 4 positions share a column)
             const int pcol = via_lds ? pos / Himg : 0, prow = via_lds ? pos - pcol * Himg : 0;
             const int lofs = (prow >> 2) * gpitch + pcol;          // prow % 4 == 0
@@ -550,6 +555,10 @@ __global__ __launch_bounds__(NT, MINW) void ss2d_scan_rows_kernel(
                     carry[ch] = fmaf(Pt, hw, St);
                 }
                 float hh = fmaf(Pe, hw, Se);
+                if (LATE_C) {
+                    const float4 cq = *reinterpret_cast<const float4*>(xd + (int64_t)(R + 1) * L + pos);
+                    Cv[0] = cq.x; Cv[1] = cq.y; Cv[2] = cq.z; Cv[3] = cq.w;
+                }
                 float yv[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -557,11 +566,26 @@ __global__ __launch_bounds__(NT, MINW) void ss2d_scan_rows_kernel(
                     hh = fmaf(a[e], hh, bb[e]);
                     yv[e] = fmaf(Cv[e], hh, Dk * xv[e]);
                 }
-                if (dir == 0) y[ch][k] = make_float4(yv[0], yv[1], yv[2], yv[3]);
-                else { y[ch][k].x += yv[0]; y[ch][k].y += yv[1]; y[ch][k].z += yv[2]; y[ch][k].w += yv[3]; }
-                // pin the result here: otherwise the optimiser sinks every step's replay down to the final stores and keeps
-                // each step's coefficients alive until then (~50 registers per tile)
-                asm volatile("" : "+v"(y[ch][k].x), "+v"(y[ch][k].y), "+v"(y[ch][k].z), "+v"(y[ch][k].w));
+                if (ORI == 1 && TR) {
+                    // the orientation-1-only launch of the row-major form keeps nothing in registers across the two directions
+                    // (64-VGPR budget): the first direction parks its result in this workgroup's own output plane in SCAN order
+                    // (coalesced, L2), the second adds it and drops the sum into the LDS slots of the x values it has just
+                    // consumed (each slot is read by its owner thread only); the write-out below then overwrites the plane.
+                    float* park = yb + (int64_t)c * L + pos;
+                    if (dir == 0) {
+                        *reinterpret_cast<float4*>(park) = make_float4(yv[0], yv[1], yv[2], yv[3]);
+                    } else {
+                        const float4 y0v = *reinterpret_cast<const float4*>(park);
+                        float* pl = plane_sm + ch * psz + lofs;
+                        pl[0] = y0v.x + yv[0]; pl[pitch] = y0v.y + yv[1]; pl[2 * pitch] = y0v.z + yv[2]; pl[3 * pitch] = y0v.w + yv[3];
+                    }
+                } else {
+                    if (dir == 0) y[ch][k] = make_float4(yv[0], yv[1], yv[2], yv[3]);
+                    else { y[ch][k].x += yv[0]; y[ch][k].y += yv[1]; y[ch][k].z += yv[2]; y[ch][k].w += yv[3]; }
+                    // pin the result here: otherwise the optimiser sinks every step's replay down to the final stores and keeps
+                    // each step's coefficients alive until then (~50 registers per tile)
+                    asm volatile("" : "+v"(y[ch][k].x), "+v"(y[ch][k].y), "+v"(y[ch][k].z), "+v"(y[ch][k].w));
+                }
             }
         }
     }
@@ -570,7 +594,7 @@ __global__ __launch_bounds__(NT, MINW) void ss2d_scan_rows_kernel(
 #pragma unroll
         for (int ch = 0; ch < CB; ++ch)
 #pragma unroll
-            for (int k = 0; k < T; ++k) {
+            for (int k = 0; k < (ORI == 1 ? 0 : T); ++k) {
                 const int pos = (k * NT + threadIdx.x) * 4, pcol = pos / Himg, prow = pos - pcol * Himg;
                 float* pl = plane_sm + ch * psz + (prow >> 2) * gpitch + pcol;
                 pl[0] = y[ch][k].x; pl[pitch] = y[ch][k].y; pl[2 * pitch] = y[ch][k].z; pl[3 * pitch] = y[ch][k].w;
@@ -861,18 +885,23 @@ extern "C" int bem_ss2d_scan_rm_supported(int H, int W, int R) {
     return H % 4 == 0 && W % 4 == 0 && ((L == 16384 && R == 3) || (L == 4096 && R == 5) || (L == 1024 && R == 10));
 }
 
-template <int NT, int T, int CB, int RT, int MW>
+// ORI = -1: one launch, both orientations (the orientation-1 workgroups stage through LDS).  ORI = 0 / 1: a launch for one
+// orientation only -- the LDS path then is a compile-time property of the kernel, its result of the first direction is parked in
+// the workgroup's own output plane instead of 16 registers, and neither variant needs scratch at the 64-register budget
+// (the combined L = 16384 kernel spilled 44 bytes per lane: 1.6x its output bytes in HBM writes).
+template <int NT, int T, int CB, int RT, int MW, int ORI>
 static int launch_rows_tr(const float* x, const float* xd0, const float* xd1, const float* dtw, const float* dtb, const float* A,
                           const float* Ds, float* y0, float* y1, int B, int C, int H, int W, int64_t xbs0, int64_t xbs1, hipStream_t s) {
-    const size_t lds = (size_t)CB * (H / 4) * (4 * (W + 1) + 1) * sizeof(float);
+    const size_t lds = ORI == 0 ? 0 : (size_t)CB * (H / 4) * (4 * (W + 1) + 1) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ss2d_scan_rows_kernel<NT, T, CB, RT, MW, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ss2d_scan_rows_kernel<NT, T, CB, RT, MW, true, ORI>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
         attr_set = true;
     }
-    ss2d_scan_rows_kernel<NT, T, CB, RT, MW, true><<<((C + CB - 1) / CB) * B * 2, NT, lds, s>>>(x, x, xd0, xd1, dtw, dtb, A, Ds, y0, y1, B, C,
-                                                                                               xbs0, xbs1, H);
+    const int groups = ((C + CB - 1) / CB) * B;
+    ss2d_scan_rows_kernel<NT, T, CB, RT, MW, true, ORI><<<ORI < 0 ? 2 * groups : groups, NT, lds, s>>>(x, x, xd0, xd1, dtw, dtb, A, Ds, y0, y1, B, C,
+                                                                                                        xbs0, xbs1, H);
     return bem_check_launch("ss2d_scan_rm");
 }
 
@@ -888,7 +917,21 @@ extern "C" int bem_ss2d_scan_rm_f32(const float* x, const float* xd0, const floa
     BEM_REQUIRE((((uintptr_t)x | (uintptr_t)xd0 | (uintptr_t)xd1 | (uintptr_t)y0 | (uintptr_t)y1) & 15) == 0, "ss2d_scan_rm: 16-byte alignment");
     if (B == 0) return BEM_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (L == 16384) return launch_rows_tr<1024, 4, 1, 3, 8>(x, xd0, xd1, dtw, dtb, A, Ds, y0, y1, B, C, H, W, xbs0, xbs1, s);
-    if (L == 4096) return launch_rows_tr<512, 2, 2, 5, 6>(x, xd0, xd1, dtw, dtb, A, Ds, y0, y1, B, C, H, W, xbs0, xbs1, s);
-    return launch_rows_tr<256, 1, 4, 10, 5>(x, xd0, xd1, dtw, dtb, A, Ds, y0, y1, B, C, H, W, xbs0, xbs1, s);
+    static const int split = getenv("BEM_SCAN_SPLIT") ? atoi(getenv("BEM_SCAN_SPLIT")) : 1;
+#define BEM_TR(NT, T, CB, RT, MW, ORI) launch_rows_tr<NT, T, CB, RT, MW, ORI>(x, xd0, xd1, dtw, dtb, A, Ds, y0, y1, B, C, H, W, xbs0, xbs1, s)
+    if (L == 16384) {
+        if (!split) return BEM_TR(1024, 4, 1, 3, 8, -1);
+        const int rc = BEM_TR(1024, 4, 1, 3, 8, 0);          // measured: 2 x 171 us against 372 us for the combined (spilling) kernel
+        return rc ? rc : BEM_TR(1024, 4, 1, 3, 8, 1);
+    }
+    if (L == 4096) {
+        if (split < 2) return BEM_TR(512, 2, 2, 5, 6, -1);
+        const int rc = BEM_TR(512, 2, 2, 5, 6, 0);
+        if (rc) return rc;
+        if (split == 2) return BEM_TR(512, 2, 2, 5, 5, 1);
+        if (split == 3) return BEM_TR(512, 2, 1, 5, 8, 1);
+        return BEM_TR(1024, 1, 2, 5, 6, 1);
+    }
+    return BEM_TR(256, 1, 4, 10, 5, -1);
+#undef BEM_TR
 }

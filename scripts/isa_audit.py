@@ -1,29 +1,214 @@
 #!/usr/bin/env python3
-"""ISA audit: per kernel, count loads that are immediately followed by a full s_waitcnt vmcnt(0)
-(= serialized memory latency), branches and MFMAs.  Usage: isa_audit.py file.hip"""
-import re, subprocess, sys, tempfile, os
-src = sys.argv[1]
-out = tempfile.mktemp(suffix=".s")
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-fast-math", "-S", "--cuda-device-only", "-o", out, src],
-               check=True, stderr=subprocess.DEVNULL, cwd="/tmp")
-name, lines = None, []
-kern = {}
-for ln in open(out):
-    m = re.match(r"^(_Z\w+):", ln)
-    if m:
-        name = m.group(1); kern[name] = []
-    if name:
-        kern[name].append(ln)
-        if "s_endpgm" in ln:
-            name = None
-for k, ls in kern.items():
-    ins = [l.split(";")[0].strip() for l in ls if l.strip() and not l.strip().startswith((";", "."))]
-    ser = 0
-    for i, l in enumerate(ins):
-        if l.startswith(("global_load", "buffer_load")):
-            nxt = [x for x in ins[i + 1:i + 4]]
-            if any(x.startswith("s_waitcnt vmcnt(0)") for x in nxt):
-                ser += 1
-    nl = sum(l.startswith(("global_load", "buffer_load")) for l in ins)
-    print(f"{k[:70]:70s} instr {len(ins):6d} loads {nl:4d} serialized {ser:4d} branches {sum(l.startswith('s_cbranch') for l in ins):4d} "
-          f"mfma {sum(l.startswith('v_mfma') for l in ins):4d} scratch {sum('scratch_' in l for l in ins):4d}")
+"""ISA audit of every kernel in csrc/*.hip (hipcc cross-compiles gfx950 without a GPU).
+
+  python scripts/isa_audit.py            table + checks; exit code 1 when a check fails
+  python scripts/isa_audit.py file.hip   one file
+
+Checks (tests/test_isa_audit.py runs them as part of the CPU suite):
+  1. scratch       `.private_segment_fixed_size` must be 0 for every kernel that is not on the ALLOW_SCRATCH list below (each entry
+                   says why the kernel is off the default path or why its spill was measured and kept).
+  2. lds -> pk     DESIGN.md section 6.4: no packed-f32 VALU instruction (v_pk_add/mul/fma_f32) may work IN PLACE on a register pair
+                   filled by an LDS read (ds_read*) while taking the pair's HIGH register for its LOW result (op_sel = 1 on that
+                   source).  On gfx950 that instruction returned the register's PRE-LOAD content in lanes 48..63 a few times per
+                   10^7 outputs when two workgroups shared a CU, with correct s_waitcnt placement (scripts/x6_bias_ab.py reproduces
+                   it with `make dbg`; LDS-loaded pairs consumed out of place -- the LayerNorm parameters of the x6 GEMMs -- ran
+                   3.8e9 outputs clean in scripts/x6_ln_stress.py).
+  3. asm loads     conv2d_mfma_pipe_kernel issues its operand loads from inline asm and waits for them in a separate asm
+                   statement: between an asm `global_load` and the asm `s_waitcnt vmcnt(0)` no compiler instruction may read,
+                   copy or spill the destination registers.
+Per kernel it also prints instruction / load / branch / MFMA counts and loads followed at once by a full vmcnt(0) wait.
+"""
+import concurrent.futures
+import glob
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "bayesian-enhancement-model_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+
+# kernel-name regex (demangled) -> reason.  Everything else must have ScratchSize == 0.
+ALLOW_SCRATCH = {
+    r"conv2d_mfma_kernel<3, 3, 1": "f32-MFMA im2col 3x3: only with BEM_CONV_X6=0 / odd widths (default 3x3 path is conv_taps_x6_kernel)",
+    r"conv2d_mfma_pipe_kernel<3, 3, 1, 1>": "3x3 with Cin % 8 != 0 and Cout <= 32 (Stage-I first_conv at 16x16): 36 B, launch-bound size",
+    r"conv2d_mfma_kernel<4, 4, 2": "4x4 stride-2 down-sampling: 1.4 % of the eval step; 16-tap x6 form measured no faster (DESIGN 6.6)",
+    r"attn_fold_kernel": "one 1024-thread workgroup per image folding 8 32x32 matrices: 8 B, ~40 us per step",
+    r"pw_gemm3_reg_kernel|pw_gemm2_kernel|pw_gemm_kernel|pw_gemm3_stream_kernel": "f32-MFMA GEMMs: only with BEM_PW_X6=0",
+    r"sample_pack_x6_kernel": "Stage-I weight sampling (Philox + Box-Muller + limb split per element, transcendental-bound): 48 B, 0.4 % of the step",
+    r"pw_x6_res_kernel<10, 1, 2": "K <= 160 with LayerNorm and all K resident (level-2 blocks, 32x32 planes): 92 B; 0.5 % of the step",
+    r"pw_x6_res_kernel<(5|10), (1|2), 1, (true|false), (true|false)>": "8 B in three rarely dispatched variants (odd L / sum input at level 1-2)",
+    r"pw_x6_stream_kernel<3, 1,": "three M-tiles x one pixel sub-tile: measured variant kept for A/B, not dispatched by default",
+    r"pw_x6_stream_kernel<2, 2, (true|false), false,": "VEC = false: odd plane sizes only (tests, ragged crops)",
+    r"pw_x6_stream_kernel<2, 2, true, true, true>": "sum input + LayerNorm at K > 160: not reached by the shipped widths (n_feat 40: K <= 160 uses the resident kernel)",
+    r"ss2d_scan_rows_kernel<.*, false, -1>": "transposed-tensor scan forms: only with BEM_SCAN_RM=0 / BEM_SCAN_VARIANT sweeps",
+    r"ss2d_scan_rows_kernel<1024, 4, 1, 3, 8, true, -1>": "combined-orientation L = 16384 form: only with BEM_SCAN_SPLIT=0 (default = two scratch-free launches)",
+    r"ss2d_scan_rows_kernel<512, 2, 2, 5, 6, true, -1>": "L = 4096 combined form: 12 B; measured 145 us against 152 us for the best scratch-free split (profiles/r02)",
+    r"ss2d_scan_rows_kernel<512, 2, [12], 5, [58], true, 1>|ss2d_scan_rows_kernel<1024, 1, 2, 5, 6, true, 1>": "L = 4096 split experiments (BEM_SCAN_SPLIT=2..4)",
+    r"ss2d_scan_bwd_kernel<1024, 4>": "general-L fallback of the scan backward (ragged planes); the shipped plane sizes use ss2d_scan_bwd_rows_kernel",
+    r"wgrad_kernel<3, 2": "checked separately: launch bound (256, 1) gives it 512 registers",
+}
+
+# check 2 exemptions: kernel-name regex -> reason
+ALLOW_LDS_PK = {
+    r"^conv2d_kernel<": "direct VALU convolution: fallback for shapes no matrix-core kernel takes (or BEM_CONV_MFMA=0); not dispatched by the shipped nets",
+}
+
+PK = re.compile(r"^v_pk_(add|mul|fma)_f32\b")
+REG = re.compile(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b")
+
+
+def compile_to_isa(src):
+    out = tempfile.mktemp(suffix=".s")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-fast-math", "-S", "--cuda-device-only", "-o", out, src],
+                       cwd=CSRC, capture_output=True, text=True)
+    if r.returncode:
+        raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-2000:]}")
+    txt = open(out).read()
+    os.unlink(out)
+    return txt
+
+
+def demangle(names):
+    r = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True)
+    return [d.replace("(anonymous namespace)::", "").replace("void ", "") for d in r.stdout.strip().split("\n")]
+
+
+def regs_of(operand_text):
+    out = set()
+    for m in REG.finditer(operand_text):
+        if m.group(1) is not None:
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        else:
+            out.add(int(m.group(3)))
+    return out
+
+
+def split_operands(ins):
+    """(mnemonic, [operand strings])"""
+    parts = ins.split(None, 1)
+    if len(parts) == 1:
+        return parts[0], []
+    ops, depth, cur = [], 0, ""
+    for ch in parts[1]:
+        if ch == "[":
+            depth += 1
+        elif ch == "]":
+            depth -= 1
+        if ch == "," and depth == 0:
+            ops.append(cur.strip()); cur = ""
+        else:
+            cur += ch
+    ops.append(cur.strip())
+    return parts[0], ops
+
+
+def audit_text(txt, fname):
+    """-> list of dict(name, file, scratch, vgprs, instr, loads, serialized, branches, mfma, lds_pk, asm_load_hazards)"""
+    meta = {}
+    for m in re.finditer(r"\.name:\s+(_Z\S+)\n((?:\s+\.\w+:.*\n)+)", txt):
+        blk = m.group(2)
+        ps = re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk)
+        vg = re.search(r"\.vgpr_count:\s+(\d+)", blk)
+        if ps:
+            meta[m.group(1)] = (int(ps.group(1)), int(vg.group(1)) if vg else -1)
+    kern, name = {}, None
+    for ln in txt.split("\n"):
+        m = re.match(r"^(_Z\w+):", ln)
+        if m and m.group(1) in meta:
+            name = m.group(1); kern[name] = []
+        if name:
+            kern[name].append(ln)
+            if "s_endpgm" in ln:
+                name = None
+    names = list(kern)
+    dem = dict(zip(names, demangle(names))) if names else {}
+    res = []
+    for k, ls in kern.items():
+        ins, in_asm, asm_flags = [], False, []
+        for l in ls:
+            t = l.strip()
+            if t.startswith(";;#ASMSTART") or t.startswith(";APP"):
+                in_asm = True; continue
+            if t.startswith(";;#ASMEND") or t.startswith(";NO_APP"):
+                in_asm = False; continue
+            t = t.split(";")[0].strip()
+            if not t or t.startswith("."):
+                continue
+            ins.append(t); asm_flags.append(in_asm)
+        ser = sum(1 for i, l in enumerate(ins) if l.startswith(("global_load", "buffer_load")) and
+                  any(x.startswith("s_waitcnt vmcnt(0)") for x in ins[i + 1:i + 4]))
+        # check 2: registers whose current value came from an LDS read, consumed by a packed-f32 op
+        from_lds, lds_pk = set(), []
+        # check 3: asm loads in flight
+        pending, asm_haz = set(), []
+        for l, ia in zip(ins, asm_flags):
+            mn, ops = split_operands(l)
+            dst = regs_of(ops[0]) if ops and not mn.startswith(("global_store", "buffer_store", "ds_write", "s_", "scratch_store", "global_atomic")) else set()
+            srcs = set()
+            for o in (ops[1:] if dst else ops):
+                srcs |= regs_of(o)
+            if PK.match(mn):
+                sel = re.search(r"op_sel:\[([01,]+)\]", l)
+                if sel:
+                    bits = sel.group(1).split(",")
+                    for i, o in enumerate(ops[1:]):
+                        # both failing builds: the op_sel source IS the destination pair (in place) and was filled by ds_read
+                        if i < len(bits) and bits[i] == "1" and (regs_of(o) & from_lds) and regs_of(o) == dst:
+                            lds_pk.append(l)
+                            break
+            if ia and mn.startswith("global_load"):
+                pending |= dst
+            elif ia and mn.startswith("s_waitcnt") and "vmcnt(0)" in l:
+                pending.clear()
+            elif not ia and pending and ((srcs | dst) & pending):
+                asm_haz.append(l)
+            if mn.startswith("ds_read"):
+                from_lds |= dst
+            else:
+                from_lds -= dst
+        res.append(dict(name=dem[k], file=fname, scratch=meta[k][0], vgprs=meta[k][1], instr=len(ins),
+                        loads=sum(l.startswith(("global_load", "buffer_load")) for l in ins), serialized=ser,
+                        branches=sum(l.startswith("s_cbranch") for l in ins), mfma=sum(l.startswith("v_mfma") for l in ins),
+                        lds_pk=lds_pk, asm_load_hazards=asm_haz))
+    return res
+
+
+def audit_all(files=None):
+    files = files or sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(files))) as ex:
+        texts = list(ex.map(compile_to_isa, files))
+    out = []
+    for f, t in zip(files, texts):
+        out += audit_text(t, os.path.basename(f))
+    return out
+
+
+def violations(kernels):
+    bad = []
+    for k in kernels:
+        if k["scratch"] and not any(re.search(p, k["name"]) for p in ALLOW_SCRATCH):
+            bad.append(f"scratch {k['scratch']} B/lane in a kernel that is not on the allow list: {k['file']}: {k['name']}")
+        if k["lds_pk"] and not any(re.search(p, k["name"]) for p in ALLOW_LDS_PK):
+            bad.append(f"packed-f32 VALU op takes the high half (op_sel) of an LDS-loaded register pair ({len(k['lds_pk'])}x, e.g. `{k['lds_pk'][0]}`): {k['file']}: {k['name']}")
+        if k["asm_load_hazards"]:
+            bad.append(f"compiler instruction touches the destination of an in-flight inline-asm load (`{k['asm_load_hazards'][0]}`): {k['file']}: {k['name']}")
+    return bad
+
+
+def main():
+    ks = audit_all([os.path.abspath(a) for a in sys.argv[1:]] or None)
+    for k in ks:
+        print(f"{k['file']:16s} {k['name'][:78]:78s} vgpr {k['vgprs']:4d} scratch {k['scratch']:4d} instr {k['instr']:6d} loads {k['loads']:4d} "
+              f"ser {k['serialized']:3d} br {k['branches']:4d} mfma {k['mfma']:4d}")
+    bad = violations(ks)
+    for b in bad:
+        print("VIOLATION:", b)
+    print(f"{len(ks)} kernels, {len(bad)} violations")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -558,6 +558,27 @@ def test_pw_gemm_x6_no_sporadic_corruption_at_load(ops, cfg):
         assert int(((y - ref).abs() > 1e-3).sum()) == 0
 
 
+def test_pw_gemm_x6_generic_epilogue_full_size(ops):
+    """The generic x6 epilogue (bias through LDS scalars): ConvTranspose2d scatter mode with bias at the config-5 decoder plane
+    (80 -> 40 channels, 112x160 -> 224x320) and an M < 8 launch, every output against torch f32 (no test covered
+    out_mode 1 / M < 8 element-wise at full size)."""
+    g = torch.Generator().manual_seed(123)
+    x = torch.randn(2, 80, 112, 160, generator=g)
+    w = torch.randn(80, 40, 2, 2, generator=g) * 80 ** -0.5
+    b = torch.randn(40, generator=g)
+    ref = F.conv_transpose2d(x, w, b, stride=2)
+    w4 = w.permute(2, 3, 1, 0).reshape(160, 80).contiguous()
+    for _ in range(3):
+        y = ops.pw_gemm(dev(x), ops.pack_pw_weight(dev(w4), x6=True), 160, bias=dev(b.repeat(4).contiguous()), convT_Win=160)
+        assert y.shape == ref.shape and int(((y.cpu() - ref).abs() > 1e-3).sum()) == 0
+    x = torch.randn(1, 40, 224, 320, generator=g)
+    w = torch.randn(5, 40, generator=g) * 40 ** -0.5
+    b = torch.randn(5, generator=g)
+    ref = torch.einsum("mk,bkhw->bmhw", w, x) + b[None, :, None, None]
+    y = ops.pw_gemm(dev(x), ops.pack_pw_weight(dev(w), x6=True), 5, bias=dev(b))
+    assert int(((y.cpu() - ref).abs() > 1e-3).sum()) == 0
+
+
 @pytest.mark.parametrize("cfg", [(2, 40, 16, 16, 12, False), (1, 40, 160, 128, 128, True), (2, 8, 32, 5, 8, True), (1, 80, 320, 9, 30, False), (3, 20, 24, 4, 6, True)])
 def test_gate_proj_vs_unfused_chain(ops, cfg):
     """bem_gate_proj_x6_f32 (depthwise 3x3 + GELU gate inside the project_out loader) against dwconv3x3(mode 2) + pw_gemm and
