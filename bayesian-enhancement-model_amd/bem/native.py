@@ -88,6 +88,7 @@ SIGNATURES = {
     "bem_iwt_f32": [P, P, I, I, I, I, P],
     "bem_iwt_hamilton_f32": [P, P, P, I, I, I, P],
     "bem_hamilton_f32": [P, P, I, I, I, P],
+    "bem_hamilton_full_f32": [P, P, P, I, I, I, P],
     "bem_attn_stats_f64": [P, P, P, I, I, P],
     "bem_attn_fold_f32": [P, P, P, P, P, P, I, I, P],
     "bem_transpose_planes_f32": [P, I64, P, I64, I, I, I, I, P],
@@ -98,6 +99,9 @@ SIGNATURES = {
     "bem_pixel_shuffle2_f32": [P, P, I, I, I, I, P],
     "bem_bnn_sample_f32": [P, P, P, P, I, I64, U64, U64, P],
     "bem_select_best_f32": [P, P, P, P, P, I, I, I64, P],
+    "bem_ssim_f32": [P, P, P, P, I, I, I, I, P],
+    "bem_select_scores_f32": [P, P, P, F, I, P, P, P, P, I, I, I64, P],
+    "bem_mc_mean_f32": [P, P, P, P, I, I, I, I, I, I, I, P],
     "bem_pad_reflect_f32": [P, P, I, I, I, I, I, P],
     "bem_resize_down_f32": [P, P, I, I, I, I, P],
     "bem_randn_f32": [P, I64, U64, U64, P],

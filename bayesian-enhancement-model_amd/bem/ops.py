@@ -504,6 +504,17 @@ def hamilton(q):
     return out
 
 
+def hamilton_full(q1, q2):
+    """QD/quaternion.py hamilton_product: (B,4,H,W) x (B,4,H,W) -> (B,4,H,W) = [real, i, j, k]."""
+    _chk(q1, "q1"); _chk(q2, "q2")
+    B, C, H, W = q1.shape
+    if C != 4 or q2.shape != q1.shape:
+        raise ValueError("hamilton_full: expects two (B,4,H,W) tensors")
+    out = torch.empty_like(q1)
+    check(lib().bem_hamilton_full_f32(_p(q1), _p(q2), _p(out), B, H, W, _stream()), "hamilton_full")
+    return out
+
+
 def attn_fold(f1, f2, attn_w, fuse_w, fuse_b):
     """Channel cross attention + fuse conv folded into per-image (32x64) weights: returns (Wp (B,2048), bias (B,32))."""
     for n, t in (("f1", f1), ("f2", f2), ("attn_w", attn_w), ("fuse_w", fuse_w), ("fuse_b", fuse_b)):
@@ -703,6 +714,51 @@ def select_best(final, psnr, samples_per_image):
     img = torch.empty((B,) + tuple(final.shape[1:]), device=final.device, dtype=final.dtype)
     check(lib().bem_select_best_f32(_p(final), _p(psnr), _p(best), _p(bp), _p(img), B, N, final[0].numel(), _stream()), "select_best")
     return best, bp, img
+
+
+def ssim(final, target, samples_per_image):
+    """Enhancement/utils.py calculate_ssim per candidate: final (Bn,3,h,w) in [0,1], target (Bn/N,3,h,w) -> (Bn) f32."""
+    _chk(final, "final"); _chk(target, "target")
+    Bn, C, h, w = final.shape
+    if C != 3 or Bn % samples_per_image or tuple(target.shape) != (Bn // samples_per_image, 3, h, w) or h <= 10 or w <= 10:
+        raise ValueError("ssim: shapes (3-channel images larger than the 11x11 window)")
+    out = torch.empty(Bn, device=final.device, dtype=torch.float32)
+    ws = torch.empty(Bn, device=final.device, dtype=torch.float64)
+    check(lib().bem_ssim_f32(_p(final), _p(target), _p(out), _p(ws), Bn, samples_per_image, h, w, _stream()), "ssim")
+    return out
+
+
+def select_scores(final, s1, samples_per_image, s2=None, weight=1.0, rule="weighted"):
+    """Per-image selection on the device (eval.py:268-297): rule 'weighted' (weight s1/max + (1-weight) s2/max), 'max', 'min';
+    first index on ties.  Returns (best (B) int32, best s1 (B), best s2 (B)|None, best images (B,3,h,w)|None)."""
+    _chk(s1, "s1"); _chk(s2, "s2", optional=True); _chk(final, "final", optional=True)
+    N = samples_per_image
+    Bn = s1.numel()
+    if Bn % N or (s2 is not None and s2.numel() != Bn) or (final is not None and final.shape[0] != Bn):
+        raise ValueError("select_scores: shapes")
+    r = {"weighted": 0, "max": 1, "min": 2}[rule]
+    B = Bn // N
+    best = torch.empty(B, device=s1.device, dtype=torch.int32)
+    b1 = torch.empty(B, device=s1.device, dtype=torch.float32)
+    b2 = torch.empty(B, device=s1.device, dtype=torch.float32) if s2 is not None else None
+    img = torch.empty((B,) + tuple(final.shape[1:]), device=s1.device, dtype=final.dtype) if final is not None else None
+    check(lib().bem_select_scores_f32(_p(final), _p(s1), _p(s2), float(weight), r, _p(best), _p(b1), _p(b2), _p(img), B, N,
+                                      (final[0].numel() if final is not None else 0), _stream()), "select_scores")
+    return best, b1, b2, img
+
+
+def mc_mean(raw, target, samples_per_image, h, w, gt_mean):
+    """Monte-Carlo mean prediction (eval.py:224-225,308-314): raw (Bn,3,Hp,Wp) -> (B,3,h,w)."""
+    _chk(raw, "raw"); _chk(target, "target", optional=True)
+    Bn, C, Hp, Wp = raw.shape
+    N = samples_per_image
+    if C != 3 or Bn % N or h > Hp or w > Wp or (gt_mean and (target is None or tuple(target.shape) != (Bn // N, 3, h, w))):
+        raise ValueError("mc_mean: shapes")
+    B = Bn // N
+    out = torch.empty(B, 3, h, w, device=raw.device, dtype=raw.dtype)
+    ws = torch.empty(2 * B, device=raw.device, dtype=torch.float64) if gt_mean else None
+    check(lib().bem_mc_mean_f32(_p(raw), _p(target if gt_mean else None), _p(out), _p(ws), B, N, Hp, Wp, h, w, int(bool(gt_mean)), _stream()), "mc_mean")
+    return out
 
 
 # --------------------------------------------------------------------------- training step ----

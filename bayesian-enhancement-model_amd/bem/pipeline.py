@@ -67,20 +67,40 @@ class BEMPipeline:
         return rel.index(max(rel))
 
     @torch.no_grad()
-    def enhance(self, imgs, targets, num_samples, gt_mean=True, deterministic=False, sync=True, **kw):
-        """candidates + per-image selection.  The selection (first maximum of psnr / max(psnr), eval.py:284-285) runs on the
-        device; with ``sync=False`` nothing is copied to the host, ``best`` / ``best_psnr`` stay device tensors and the
-        caller may enqueue the next batch at once (bench.py does)."""
+    def enhance(self, imgs, targets, num_samples, gt_mean=True, deterministic=False, sync=True, scorer=None, monte_carlo=False, **kw):
+        """candidates + per-image selection.  Default selection = the full-reference PSNR rule (first maximum of psnr / max(psnr),
+        eval.py:284-285) on the device; ``scorer`` (bem.scorers) switches to the PSNR/SSIM-weighted rule or a no-reference
+        scorer (eval.py:268-281).  ``monte_carlo``: also returns the Monte-Carlo mean prediction (eval.py:224-225,308-314) with its
+        PSNR / SSIM.  With ``sync=False`` nothing is copied to the host."""
         r = self.candidates(imgs, targets, num_samples, gt_mean, deterministic, **kw)
         N = r["N"]
-        best, bp, img = ops.select_best(r["final"], r["psnr"], N)
-        if targets is None:
-            best = torch.zeros_like(best)          # no reference: the reference keeps the first sample
-            img = r["final"][::N].contiguous()
+        h, w = imgs.shape[-2:]
+        if scorer is not None:
+            sel = scorer.select(r["final"], targets, N, psnr=r["psnr"])
+            best, img = sel["best"], sel["best_images"]
+            bp = ops.select_scores(None, r["psnr"], N, rule="max")[1] if targets is None else _gather(r["psnr"], best, N)
+            r.update(scores=sel["s1"], scores2=sel["s2"])
+        else:
+            best, bp, img = ops.select_best(r["final"], r["psnr"], N)
+            if targets is None:
+                best = torch.zeros_like(best)          # no reference: the reference keeps the first sample (eval.py:291-293)
+                img = r["final"][::N].contiguous()
         r.update(best=best, best_images=img, best_psnr=bp)
+        if monte_carlo:
+            mc = ops.mc_mean(r["raw"], None if targets is None else targets.contiguous(), N, h, w, bool(gt_mean and targets is not None))
+            r["mc"] = mc
+            if targets is not None:
+                _, r["mc_psnr"] = ops.candidate_finalize(mc, targets.contiguous(), 1, h, w, False)
+                r["mc_ssim"] = ops.ssim(mc, targets.contiguous(), 1) if min(h, w) > 10 else None
         if sync:
             r["best"], r["best_psnr"] = best.cpu().tolist(), bp.cpu().tolist()
         return r
+
+
+def _gather(v, best, N):
+    """v (B*N), best (B) -> v[b*N + best[b]] on the device (index arithmetic only)."""
+    B = best.numel()
+    return v.view(B, N).gather(1, best.long().view(B, 1)).view(B)
 
 
 # ------------------------------------------------------------------------------------------------

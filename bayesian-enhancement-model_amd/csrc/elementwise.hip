@@ -139,6 +139,22 @@ __global__ void hamilton_kernel(const float* __restrict__ q, float* __restrict__
     op[0] = o[0]; op[HW] = o[1]; op[2 * HW] = o[2];
 }
 
+// all four components (real part first), the reference's hamilton_product (QD/quaternion.py:3-17)
+__global__ void hamilton_full_kernel(const float* __restrict__ q1, const float* __restrict__ q2, float* __restrict__ out, int64_t HW, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t pix = i % HW, b = i / HW;
+    const float* p = q1 + b * 4 * HW + pix;
+    const float* q = q2 + b * 4 * HW + pix;
+    const float pp[4] = {p[0], p[HW], p[2 * HW], p[3 * HW]};
+    const float qq[4] = {q[0], q[HW], q[2 * HW], q[3 * HW]};
+    float o[3];
+    hamilton_ijk(pp, qq, o);
+    float* op = out + b * 4 * HW + pix;
+    op[0] = pp[0] * qq[0] - pp[1] * qq[1] - pp[2] * qq[2] - pp[3] * qq[3];
+    op[HW] = o[0]; op[2 * HW] = o[1]; op[3 * HW] = o[2];
+}
+
 // ---------------------------------------------------------------- channel attention ----------
 // stats[b] = { S[32][32] = F1 F2^T, s1[32] = F1 1, s2[32] = F2 1 } accumulated in f64.
 constexpr int ATT_C = 32;
@@ -574,6 +590,129 @@ __global__ void gather_best_scalar_kernel(const float* __restrict__ cand, const 
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < chw; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
+// ---------------------------------------------------------------- SSIM (Enhancement/utils.py:12-57) ----------
+// calculate_ssim(img_as_ubyte(target), img_as_ubyte(pred)): per channel, on the uint8 VALUES rint(255 x) in float64, 11x11 Gaussian
+// window (sigma 1.5, cv2.getGaussianKernel(11, 1.5) = normalised exp(-(i - 5)^2 / (2 sigma^2))), "valid" region [5:-5, 5:-5],
+// ssim_map = (2 mu1 mu2 + C1)(2 s12 + C2) / ((mu1^2 + mu2^2 + C1)(s1 + s2 + C2)), mean over the region, mean over the 3 channels.
+// One workgroup = a 16 x 16 tile of the valid region of one (candidate, channel): both 26 x 26 input tiles staged in LDS.
+constexpr int SS_T = 16, SS_K = 11, SS_IN = SS_T + SS_K - 1;
+__global__ __launch_bounds__(256) void ssim_kernel(const float* __restrict__ pred, const float* __restrict__ target, double* __restrict__ acc,
+                                                  int spi, int h, int w) {
+    __shared__ float sa[SS_IN][SS_IN + 1], sb[SS_IN][SS_IN + 1];
+    __shared__ double gk[SS_K];
+    __shared__ double red[4];
+    const int vw = w - 10, vh = h - 10;
+    const int tiles_x = (vw + SS_T - 1) / SS_T;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
+    const int ch = blockIdx.y, bn = blockIdx.z;
+    const float* pa = target + ((int64_t)(bn / spi) * 3 + ch) * h * w;     // img1 = target, img2 = candidate
+    const float* pb = pred + ((int64_t)bn * 3 + ch) * h * w;
+    if (threadIdx.x < SS_K) {
+        double sum = 0.0;
+        for (int i = 0; i < SS_K; ++i) sum += exp(-(double)((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5));
+        gk[threadIdx.x] = exp(-(double)((threadIdx.x - 5) * ((int)threadIdx.x - 5)) / (2.0 * 1.5 * 1.5)) / sum;
+    }
+    for (int i = threadIdx.x; i < SS_IN * SS_IN; i += 256) {
+        const int r = i / SS_IN, c = i % SS_IN;
+        const int y = min(ty * SS_T + r, h - 1), x = min(tx * SS_T + c, w - 1);
+        sa[r][c] = rintf(fminf(fmaxf(pa[(int64_t)y * w + x], 0.f), 1.f) * 255.f);     // img_as_ubyte: rint(255 x), half to even
+        sb[r][c] = rintf(fminf(fmaxf(pb[(int64_t)y * w + x], 0.f), 1.f) * 255.f);
+    }
+    __syncthreads();
+    const int oy = threadIdx.x / SS_T, ox = threadIdx.x % SS_T;
+    double v = 0.0;
+    if (ty * SS_T + oy < vh && tx * SS_T + ox < vw) {
+        double m1 = 0, m2 = 0, s11 = 0, s22 = 0, s12 = 0;
+        for (int i = 0; i < SS_K; ++i) {
+            double r1 = 0, r2 = 0, r11 = 0, r22 = 0, r12 = 0;
+#pragma unroll
+            for (int j = 0; j < SS_K; ++j) {
+                const double a = sa[oy + i][ox + j], b = sb[oy + i][ox + j], g = gk[j];
+                r1 += g * a; r2 += g * b; r11 += g * a * a; r22 += g * b * b; r12 += g * a * b;
+            }
+            const double g = gk[i];
+            m1 += g * r1; m2 += g * r2; s11 += g * r11; s22 += g * r22; s12 += g * r12;
+        }
+        const double C1 = (0.01 * 255) * (0.01 * 255), C2 = (0.03 * 255) * (0.03 * 255);
+        const double m11 = m1 * m1, m22 = m2 * m2, m12 = m1 * m2;
+        v = ((2 * m12 + C1) * (2 * (s12 - m12) + C2)) / ((m11 + m22 + C1) * ((s11 - m11) + (s22 - m22) + C2));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc + bn, red[0] + red[1] + red[2] + red[3]);
+}
+__global__ void ssim_final_kernel(const double* __restrict__ acc, float* __restrict__ out, int Bn, double inv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < Bn) out[i] = (float)(acc[i] * inv);
+}
+
+// Generalised selection of eval.py:268-297.  rule 0: first maximum of w s1 / max(s1) + (1 - w) s2 / max(s2) (full reference,
+// :284-285; s2 = NULL means w = 1); rule 1: first maximum of s1 (no-reference CLIP-IQA, :271); rule 2: first minimum of s1 (NIQE,
+// :273-274).  f64 like the reference's python floats; one thread per image.
+__global__ void select_scores_kernel(const float* __restrict__ s1, const float* __restrict__ s2, double w, int rule, int* __restrict__ best,
+                                     float* __restrict__ best_s1, float* __restrict__ best_s2, int B, int N) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* p = s1 + (int64_t)b * N;
+    const float* q = s2 ? s2 + (int64_t)b * N : nullptr;
+    int bi = 0;
+    if (rule == 0) {
+        double m1 = (double)p[0], m2 = q ? (double)q[0] : 1.0;
+        for (int i = 1; i < N; ++i) { m1 = fmax(m1, (double)p[i]); if (q) m2 = fmax(m2, (double)q[i]); }
+        double bs = -1e300;
+        for (int i = 0; i < N; ++i) {
+            const double sc = q ? w * (double)p[i] / m1 + (1.0 - w) * (double)q[i] / m2 : (double)p[i] / m1;
+            if (sc > bs) { bs = sc; bi = i; }
+        }
+    } else {
+        double bs = (double)p[0];
+        for (int i = 1; i < N; ++i) {
+            const double sc = (double)p[i];
+            if (rule == 1 ? sc > bs : sc < bs) { bs = sc; bi = i; }
+        }
+    }
+    best[b] = bi;
+    if (best_s1) best_s1[b] = p[bi];
+    if (best_s2 && q) best_s2[b] = q[bi];
+}
+
+// Monte-Carlo mean of eval.py:224-225,308-314: mc = clamp(mean_n clamp(pred_n[:h,:w], 0, 1), 0, 1); with GT-mean the whole image is
+// scaled by mean(gray(target)) / mean(gray(mc)), gray = cv2.COLOR_BGR2GRAY of the array as stored (0.114 c0 + 0.587 c1 + 0.299 c2).
+__global__ __launch_bounds__(256) void mc_mean_kernel(const float* __restrict__ pred, float* __restrict__ out, double* __restrict__ gsum,
+                                                     const float* __restrict__ target, int N, int Hp, int Wp, int h, int w) {
+    __shared__ double sh[2][4];
+    const int ch = blockIdx.y, b = blockIdx.z;
+    const float gw = ch == 0 ? 0.114f : (ch == 1 ? 0.587f : 0.299f);
+    double sm = 0.0, st = 0.0;
+    const int64_t hw = (int64_t)h * w;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += (int64_t)gridDim.x * 256) {
+        const int y = (int)(i / w), x = (int)(i % w);
+        float a = 0.f;
+        for (int n = 0; n < N; ++n) a += fminf(fmaxf(pred[(((int64_t)b * N + n) * 3 + ch) * Hp * Wp + (int64_t)y * Wp + x], 0.f), 1.f);
+        a = fminf(fmaxf(a / (float)N, 0.f), 1.f);
+        out[((int64_t)b * 3 + ch) * hw + i] = a;
+        sm += (double)(gw * a);
+        if (target) st += (double)(gw * target[((int64_t)b * 3 + ch) * hw + i]);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { sm += __shfl_xor(sm, d, 64); st += __shfl_xor(st, d, 64); }
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = sm; sh[1][threadIdx.x >> 6] = st; }
+    __syncthreads();
+    if (threadIdx.x == 0 && gsum) {
+        atomicAdd(gsum + 2 * b, sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]);
+        atomicAdd(gsum + 2 * b + 1, sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
+    }
+}
+__global__ void mc_rescale_kernel(float* __restrict__ out, const double* __restrict__ gsum, int64_t chw, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t b = i / chw;
+    const float ratio = (float)(gsum[2 * b + 1] / gsum[2 * b]);
+    out[i] = fminf(fmaxf(out[i] * ratio, 0.f), 1.f);
+}
+
 }  // namespace
 
 // ================================================================ C ABI =========================
@@ -611,6 +750,14 @@ extern "C" int bem_iwt_hamilton_f32(const float* q1w, const float* q2w, float* o
     const int64_t total = (int64_t)B * h * w;
     iwt_hamilton_kernel<<<GRID1D(total), 256, 0, (hipStream_t)stream>>>(q1w, q2w, out, h, w, total);
     return bem_check_launch("iwt_hamilton");
+}
+
+extern "C" int bem_hamilton_full_f32(const float* q1, const float* q2, float* out, int B, int H, int W, void* stream) {
+    BEM_REQUIRE(q1 && q2 && out && B >= 0 && H > 0 && W > 0, "hamilton_full: bad arguments");
+    if (B == 0) return BEM_OK;
+    const int64_t total = (int64_t)B * H * W;
+    hamilton_full_kernel<<<GRID1D(total), 256, 0, (hipStream_t)stream>>>(q1, q2, out, (int64_t)H * W, total);
+    return bem_check_launch("hamilton_full");
 }
 
 extern "C" int bem_hamilton_f32(const float* q, float* out, int B, int H, int W, void* stream) {
@@ -786,4 +933,50 @@ extern "C" int bem_select_best_f32(const float* cand, const float* psnr, int* be
         else gather_best_scalar_kernel<<<grid, 256, 0, s>>>(cand, best, best_img, N, n);
     }
     return bem_check_launch("select_best");
+}
+
+extern "C" int bem_ssim_f32(const float* pred, const float* target, float* ssim, double* ws, int Bn, int samples_per_image, int h, int w, void* stream) {
+    BEM_REQUIRE(pred && target && ssim && ws, "ssim: null tensor");
+    BEM_REQUIRE(Bn >= 0 && Bn <= 65535 && samples_per_image >= 1 && Bn % samples_per_image == 0 && h > 10 && w > 10, "ssim: bad shape (images larger than the 11x11 window)");
+    if (Bn == 0) return BEM_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(ws, 0, sizeof(double) * Bn, s) != hipSuccess) return bem_check_launch("ssim memset");
+    const int tiles = cdiv(h - 10, SS_T) * cdiv(w - 10, SS_T);
+    ssim_kernel<<<dim3(tiles, 3, Bn), 256, 0, s>>>(pred, target, ws, samples_per_image, h, w);
+    ssim_final_kernel<<<cdiv(Bn, 64), 64, 0, s>>>(ws, ssim, Bn, 1.0 / (3.0 * (double)(h - 10) * (double)(w - 10)));
+    return bem_check_launch("ssim");
+}
+
+extern "C" int bem_select_scores_f32(const float* cand, const float* s1, const float* s2, float weight, int rule, int* best, float* best_s1,
+                                     float* best_s2, float* best_img, int B, int N, int64_t chw, void* stream) {
+    BEM_REQUIRE(s1 && best, "select_scores: null tensor");
+    BEM_REQUIRE(B >= 0 && B <= 65535 && N >= 1 && chw >= 0 && rule >= 0 && rule <= 2, "select_scores: bad arguments");
+    BEM_REQUIRE((cand == nullptr) == (best_img == nullptr), "select_scores: cand and best_img go together");
+    if (B == 0) return BEM_OK;
+    hipStream_t s = (hipStream_t)stream;
+    select_scores_kernel<<<cdiv(B, 64), 64, 0, s>>>(s1, s2, (double)weight, rule, best, best_s1, best_s2, B, N);
+    if (cand && chw > 0) {
+        const bool v4 = chw % 4 == 0 && (((uintptr_t)cand | (uintptr_t)best_img) & 15) == 0;
+        const int64_t n = v4 ? chw / 4 : chw;
+        dim3 grid((unsigned)std::min<int64_t>(cdiv64(n, 256), 1024), B);
+        if (v4) gather_best_kernel<<<grid, 256, 0, s>>>(cand, best, best_img, N, n);
+        else gather_best_scalar_kernel<<<grid, 256, 0, s>>>(cand, best, best_img, N, n);
+    }
+    return bem_check_launch("select_scores");
+}
+
+extern "C" int bem_mc_mean_f32(const float* pred, const float* target, float* out, double* ws, int B, int N, int Hp, int Wp, int h, int w,
+                               int gt_mean, void* stream) {
+    BEM_REQUIRE(pred && out && B >= 0 && B <= 65535 && N >= 1 && h > 0 && w > 0 && h <= Hp && w <= Wp, "mc_mean: bad arguments");
+    BEM_REQUIRE(!gt_mean || (target && ws), "mc_mean: GT-mean needs the target and a scratch of 2 B doubles");
+    if (B == 0) return BEM_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (gt_mean && hipMemsetAsync(ws, 0, sizeof(double) * 2 * B, s) != hipSuccess) return bem_check_launch("mc_mean memset");
+    const unsigned gx = (unsigned)std::min<int64_t>(cdiv64((int64_t)h * w, 256), 256);
+    mc_mean_kernel<<<dim3(gx, 3, B), 256, 0, s>>>(pred, out, gt_mean ? ws : nullptr, gt_mean ? target : nullptr, N, Hp, Wp, h, w);
+    if (gt_mean) {
+        const int64_t total = (int64_t)B * 3 * h * w;
+        mc_rescale_kernel<<<GRID1D(total), 256, 0, s>>>(out, ws, (int64_t)3 * h * w, total);
+    }
+    return bem_check_launch("mc_mean");
 }

@@ -202,6 +202,9 @@ int bem_iwt_hamilton_f32(const float* q1w, const float* q2w, float* out, int B, 
 /* Hamilton product of q[:, 0:4] and q[:, 4:8] (B,8,H,W), real part dropped -> (B,3,H,W). */
 int bem_hamilton_f32(const float* q, float* out, int B, int H, int W, void* stream);
 
+/* hamilton_product(q1, q2) of QD/quaternion.py:3-17: q1, q2 (B,4,H,W) -> out (B,4,H,W) = [real, i, j, k]. */
+int bem_hamilton_full_f32(const float* q1, const float* q2, float* out, int B, int H, int W, void* stream);
+
 /* Channel cross-attention of the decomposition net (QD/model4.py:81-139) folded with the 1x1 `fuse`
  * conv that follows it.  Step 1: accumulate per image S = F1 F2^T (32x32), s1 = F1 1, s2 = F2 1 in f64
  * (stats: (B, 32*32 + 64) doubles, zeroed by the call).  Step 2: softmax + fold all 1x1 weights into
@@ -264,6 +267,24 @@ int bem_candidate_finalize_f32(const float* pred, const float* target, float* fi
  * best_img[b] = cand[b*N + best[b]] (chw floats each).  Everything stays on the device: no host round trip per step. */
 int bem_select_best_f32(const float* cand, const float* psnr, int* best, float* best_psnr, float* best_img, int B, int N,
                         int64_t chw, void* stream);
+
+/* calculate_ssim(img_as_ubyte(target), img_as_ubyte(pred)) of Enhancement/utils.py:12-57 per candidate: uint8 values rint(255 x), f64,
+ * 11x11 Gaussian (sigma 1.5) over the valid region, mean over region and channels.  pred (Bn,3,h,w), target (Bn/spi,3,h,w), h, w > 10;
+ * ssim (Bn) f32 out; ws: scratch of Bn doubles (zeroed by the call). */
+int bem_ssim_f32(const float* pred, const float* target, float* ssim, double* ws, int Bn, int samples_per_image, int h, int w, void* stream);
+
+/* Selection rules of eval.py:268-297 on the device, FIRST index on ties (python list.index):
+ *   rule 0: max of weight * s1 / max(s1) + (1 - weight) * s2 / max(s2)  (full reference, PSNR / SSIM; s2 NULL = weight 1)
+ *   rule 1: max of s1 (no-reference, CLIP-IQA)      rule 2: min of s1 (NIQE)
+ * best (B) int32; best_s1 / best_s2 (B) or NULL; best_img[b] = cand[b*N + best[b]] when cand / best_img are given. */
+int bem_select_scores_f32(const float* cand, const float* s1, const float* s2, float weight, int rule, int* best, float* best_s1,
+                          float* best_s2, float* best_img, int B, int N, int64_t chw, void* stream);
+
+/* Monte-Carlo mean of eval.py:224-225,308-314: out (B,3,h,w) = clamp(mean_n clamp(pred[b*N+n][:, :h, :w], 0, 1), 0, 1), with gt_mean scaled
+ * by mean(gray(target)) / mean(gray(out)) (cv2 BGR2GRAY weights on the stored channel order) and clipped.  pred (B*N,3,Hp,Wp);
+ * ws: 2 B doubles (zeroed by the call) when gt_mean. */
+int bem_mc_mean_f32(const float* pred, const float* target, float* out, double* ws, int B, int N, int Hp, int Wp, int h, int w,
+                    int gt_mean, void* stream);
 
 /* gdMlp tail (vmamba.py:124-133) in one kernel: out = res + W_o * ( GELU(dw3x3(h)[0:Hd]) * dw3x3(h)[Hd:2Hd] ) + bias.
  * h (B,2Hd,H,W) = project_in output; it must be readable ONE ELEMENT BEFORE ITS FIRST AND AFTER ITS LAST element (the 3x3

@@ -587,3 +587,65 @@ def train_step_ref(sd: SD, lq, gt, conds, *, stage2=ddwavelet_ref, scale=16, lr=
         losses.append(float(loss))
         norms.append(float(gn))
     return dict(loss=losses, grad_norm=norms, grads=grads0, params={k: v.detach() for k, v in params.items()}, out=out.detach())
+
+
+# ----------------------------------------------------------------------------------------------
+# A12  selection metrics and rules      Enhancement/utils.py:12-57, Enhancement/eval.py:224-225,268-297,308-314
+# ----------------------------------------------------------------------------------------------
+
+def ssim_ref(img1, img2):
+    """calculate_ssim(img1, img2) for (h,w,3) uint8-valued arrays: per channel, float64, cv2.getGaussianKernel(11, 1.5) outer product,
+    cv2.filter2D(...)[5:-5, 5:-5] (the valid region: the border mode never matters), constants (0.01*255)^2, (0.03*255)^2.
+    cv2 is not installed anywhere here; the Gaussian kernel is its documented closed form (normalised exp(-(i-5)^2 / (2 sigma^2)) for
+    ksize 11 > 7), the correlation is restated with numpy -- values parity-unpinned against cv2 itself, formula from utils.py."""
+    import numpy as np
+    g = np.exp(-((np.arange(11) - 5.0) ** 2) / (2 * 1.5 ** 2))
+    g /= g.sum()
+    win = np.outer(g, g)
+
+    def filt(a):
+        h, w = a.shape
+        out = np.zeros((h - 10, w - 10))
+        for i in range(11):
+            for j in range(11):
+                out += win[i, j] * a[i:i + h - 10, j:j + w - 10]
+        return out
+    C1, C2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+    vals = []
+    for c in range(3):
+        a, b = img1[:, :, c].astype(np.float64), img2[:, :, c].astype(np.float64)
+        mu1, mu2 = filt(a), filt(b)
+        s1, s2, s12 = filt(a * a) - mu1 ** 2, filt(b * b) - mu2 ** 2, filt(a * b) - mu1 * mu2
+        vals.append((((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 ** 2 + mu2 ** 2 + C1) * (s1 + s2 + C2))).mean())
+    return float(np.mean(vals))
+
+
+def img_as_ubyte_ref(x):
+    """skimage.util.img_as_ubyte for float images in [0,1]: rint(255 x) (round half to even) as uint8."""
+    import numpy as np
+    return np.rint(np.clip(x, 0, 1) * 255.0).astype(np.uint8)
+
+
+def select_ref(psnr_list=None, ssim_list=None, psnr_weight=1.0, no_ref_list=None, no_ref="", ):
+    """eval.py:268-297: index of the chosen candidate.  no_ref 'clip' -> index(max), 'niqe' -> index(min); otherwise the weighted
+    full-reference rule :284-285.  Python list semantics (first occurrence)."""
+    import numpy as np
+    if no_ref == "clip":
+        return no_ref_list.index(max(no_ref_list))
+    if no_ref == "niqe":
+        return no_ref_list.index(min(no_ref_list))
+    best = (psnr_weight * np.array(psnr_list) / max(psnr_list) + (1 - psnr_weight) * np.array(ssim_list) / max(ssim_list)).tolist()
+    return best.index(max(best))
+
+
+def mc_mean_ref(preds_hw3, target_hw3=None, gt_mean=False):
+    """eval.py:224-225,308-314: preds (N,h,w,3) clamped candidates -> clamp(mean) and the gray-mean GT rescale
+    (cv2.COLOR_BGR2GRAY weights 0.114, 0.587, 0.299 on the stored channel order)."""
+    import numpy as np
+    mc = np.clip(np.mean(np.clip(preds_hw3, 0, 1), axis=0), 0, 1)
+    if gt_mean:
+        wts = np.array([0.114, 0.587, 0.299], dtype=np.float32)
+        gm = float((mc.astype(np.float32) * wts).sum(-1).mean())
+        gtm = float((target_hw3.astype(np.float32) * wts).sum(-1).mean())
+        mc = np.clip(mc * (gtm / gm), 0, 1)
+    return mc

@@ -4,7 +4,9 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, qd_state_dict
+import os
+
+from conftest import PKG, load_golden, qd_state_dict
 from oracle import bem_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -283,3 +285,54 @@ def test_stage2_within_f32_rounding_of_float64():
     e_ref, e_hip = (r32.double() - r64).abs(), (out - r64).abs()
     print(f"vs float64: reference f32 mean {e_ref.mean():.3e} max {e_ref.max():.3e} | HIP mean {e_hip.mean():.3e} max {e_hip.max():.3e}")
     assert e_hip.mean() <= 2 * e_ref.mean() + 1e-7 and e_hip.max() <= 2 * e_ref.max() + 1e-6
+
+
+def test_pipeline_scorers_and_monte_carlo():
+    """enhance() with the pluggable scorers: PSNR/SSIM-weighted full-reference rule and the CLIP stand-in (no-reference, index(max))
+    choose what eval.py's list arithmetic chooses from the same score vectors; the Monte-Carlo mean comes with its PSNR / SSIM."""
+    from bem.pipeline import BEMPipeline, build_nets, synthetic_pair
+    from bem.scorers import ClipStandIn, FullReference
+    net1, net2 = build_nets(n_feat=8, num_blocks=(1, 1, 1), seed=100, device="cuda")
+    lq, gt = synthetic_pair((2, 3, 64, 64))
+    pipe = BEMPipeline(net1, net2)
+    N = 4
+    r = pipe.enhance(lq.cuda(), gt.cuda(), N, gt_mean=True, seed=3, scorer=FullReference(0.4), monte_carlo=True)
+    ps, ss = r["scores"].cpu().view(2, N), r["scores2"].cpu().view(2, N)
+    assert r["best"] == [O.select_ref(ps[b].double().tolist(), ss[b].double().tolist(), 0.4) for b in range(2)]
+    fin = r["final"].cpu()
+    for bn in (0, 5):
+        ref = O.ssim_ref(O.img_as_ubyte_ref(gt[bn // N].permute(1, 2, 0).numpy()), O.img_as_ubyte_ref(fin[bn].permute(1, 2, 0).numpy()))
+        assert abs(float(ss.view(-1)[bn]) - ref) < 1e-6
+    assert r["mc"].shape == (2, 3, 64, 64) and r["mc_psnr"].shape == (2,) and r["mc_ssim"].shape == (2,)
+    pr = r["raw"].cpu()[:N, :, :64, :64].permute(0, 2, 3, 1).numpy()
+    close(r["mc"][0].permute(1, 2, 0), torch.from_numpy(O.mc_mean_ref(pr, gt[0].permute(1, 2, 0).numpy(), True)), 2e-6, 2e-6, "mc")
+    r2 = pipe.enhance(lq.cuda(), None, N, gt_mean=False, seed=3, scorer=ClipStandIn())
+    s = r2["scores"].cpu().view(2, N)
+    assert r2["best"] == [O.select_ref(no_ref_list=s[b].tolist(), no_ref="clip") for b in range(2)]
+
+
+def test_eval_driver_cli(tmp_path):
+    """Enhancement/eval.py with the reference's command line on two synthetic PNG pairs and seeded random checkpoints: runs, writes
+    one PNG per input and result.txt, and its Best_PSNR equals the pipeline's own selection on the same inputs and seed."""
+    import importlib.util
+    from PIL import Image
+    from bem.pipeline import BEMPipeline, build_nets, synthetic_pair
+    spec = importlib.util.spec_from_file_location("bem_eval_driver", os.path.join(PKG, "Enhancement", "eval.py"))
+    drv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(drv)
+    net1, net2 = build_nets(device="cpu")
+    torch.save({"params": net1.state_dict()}, tmp_path / "cg.pth")
+    torch.save({"params": {k: v for k, v in net2.state_dict().items()}}, tmp_path / "s2.pth")
+    (tmp_path / "in").mkdir(); (tmp_path / "gt").mkdir()
+    lq, gt = synthetic_pair((2, 3, 64, 64))
+    for i in range(2):
+        for d, t in (("in", lq), ("gt", gt)):
+            Image.fromarray(np.rint(t[i].permute(1, 2, 0).numpy() * 255).astype(np.uint8)).save(tmp_path / d / f"{i}.png")
+    out = drv.main(["--opt", os.path.join(PKG, "Options", "CG_UNet_LOLv1.yml"), "--cond_opt", os.path.join(PKG, "Options", "DecompDualBranch2DDWavelet_4.yml"),
+                    "--weights", str(tmp_path / "cg.pth"), "--cond_weights", str(tmp_path / "s2.pth"), "--input_dir", str(tmp_path / "in"),
+                    "--target_dir", str(tmp_path / "gt"), "--result_dir", str(tmp_path / "res"), "--dataset", "synthetic", "--GT_mean",
+                    "--num_samples", "3", "--psnr_weight", "0.5", "--Monte_Carlo", "--seed", "11"])
+    assert sorted(os.listdir(out["result_dir"])) == ["0.png", "1.png", "result.txt"]
+    txt = open(os.path.join(out["result_dir"], "result.txt")).read()
+    assert "Best_PSNR" in txt and "Best_SSIM" in txt and "MC_PSNR" in txt
+    assert len(out["psnr"]) == 2 and all(5 < p < 100 for p in out["psnr"]) and all(0 < s <= 1 for s in out["ssim"])

@@ -622,3 +622,89 @@ def test_ss2d_scan_row_major_form(ops, shape):
     r0, r1 = ops.ss2d_scan(x.view(B, C, L), xT.view(B, C, L), xd0, xd1, dtw, dtb, A, Ds)
     assert torch.equal(y0.view(B, C, L), r0)
     assert torch.equal(y1, ops.transpose_planes(r1.view(B, C, W, H)))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# native seam: the module the reference's csms6s.py imports
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["a", "b", "d", "e"])
+def test_selective_scan_cuda_oflex_module(tag):
+    """``selective_scan_cuda_oflex.fwd`` / ``.bwd`` called with the reference's own argument lists (csms6s.py:85,101) against the
+    outputs and the seven gradients recorded from the reference (g1_scan_*.npz); tolerances of test_selective_scan.py:398-405."""
+    import selective_scan_cuda_oflex as ext
+    g = load_golden(f"g1_scan_{tag}")
+    u, delta, A, B, C = (dev(g[k]) for k in ("u", "delta", "A", "B", "C"))
+    D = dev(g["D"]) if "D" in g else None
+    bias = dev(g["delta_bias"]) if "delta_bias" in g else None
+    out, x, *rest = ext.fwd(u, delta, A, B, C, D, bias, True, 1, True)
+    assert out.dtype == torch.float32 and x.shape == (u.shape[0], u.shape[1], (u.shape[2] + 2047) // 2048, 2 * A.shape[1]) and not rest
+    close(out, g["y"], 6e-4, 2e-3, "fwd")
+    du, dd, dA, dB, dC, dD, db, *rest = ext.bwd(u, delta, A, B, C, D, bias, dev(g["dout"]), x, True, 1)
+    for name, got in (("du", du), ("ddelta", dd), ("dA", dA), ("dB", dB), ("dC", dC), ("dD", dD), ("dbias", db)):
+        if name in g:
+            close(got, g[name], 6e-3, 2e-2, name)
+        else:
+            assert got is None
+    # half-precision inputs: computed in f32, du / ddelta come back in the input dtype, out_float=False returns the input dtype
+    o16, _ = ext.fwd(u.half(), delta.half(), A, B.half(), C.half(), D, bias, True, 1, False)
+    assert o16.dtype == torch.float16
+    with pytest.raises(RuntimeError):
+        ext.fwd(u.cpu(), delta.cpu(), A.cpu(), B.cpu(), C.cpu(), None, None, True, 1, True)
+    with pytest.raises(RuntimeError):
+        ext.fwd(u, delta, A.double(), B, C, D, bias, True, 1, True)
+
+
+def test_hamilton_product_reference_name():
+    from basicsr.QD.quaternion import hamilton_product
+    g = load_golden("g3_haar")
+    close(hamilton_product(dev(g["p"]), dev(g["q"])), g["ham"], 1e-6, 1e-6, "hamilton_product")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# selection metrics and rules (eval.py:224-225,268-297,308-314; Enhancement/utils.py:12-57)
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,N,h,w", [(2, 3, 37, 45), (1, 2, 64, 64), (1, 1, 11 + 16, 11 + 1)])
+def test_ssim_matches_utils_formula(ops, B, N, h, w):
+    """bem_ssim_f32 against the oracle's restatement of calculate_ssim(img_as_ubyte(target), img_as_ubyte(pred)) (float64, 11x11
+    Gaussian, valid region).  Tolerance 1e-6: the kernel is float64 too, only the summation order differs."""
+    g = torch.Generator().manual_seed(h * w)
+    tg = torch.rand(B, 3, h, w, generator=g)
+    fin = (tg[:, None] + 0.1 * torch.randn(B, N, 3, h, w, generator=g)).clamp(0, 1).reshape(B * N, 3, h, w)
+    got = ops.ssim(dev(fin), dev(tg), N).cpu()
+    for bn in range(B * N):
+        ref = O.ssim_ref(O.img_as_ubyte_ref(tg[bn // N].permute(1, 2, 0).numpy()), O.img_as_ubyte_ref(fin[bn].permute(1, 2, 0).numpy()))
+        assert abs(float(got[bn]) - ref) < 1e-6, (bn, float(got[bn]), ref)
+
+
+def test_select_scores_rules(ops):
+    """Weighted PSNR/SSIM rule, index(max), index(min) -- first index on ties, negative maxima, against eval.py's list arithmetic."""
+    g = torch.Generator().manual_seed(5)
+    B, N = 6, 5
+    ps = torch.rand(B, N, generator=g) * 10 + 15
+    ss = torch.rand(B, N, generator=g) * 0.3 + 0.6
+    ps[1, 3] = ps[1, 1] = ps[1].max() + 1.0            # tie: the first of the two wins
+    ss[1, 3] = ss[1, 1]
+    ps[2] = -ps[2]                                      # negative PSNRs: dividing by a negative maximum flips the order, as in the reference
+    fin = torch.rand(B * N, 3, 4, 4, generator=g)
+    for wgt in (1.0, 0.5, 0.0):
+        best, b1, b2, img = ops.select_scores(dev(fin), dev(ps.reshape(-1)), N, dev(ss.reshape(-1)), wgt, "weighted")
+        ref = [O.select_ref(ps[b].double().tolist(), ss[b].double().tolist(), wgt) for b in range(B)]
+        assert best.cpu().tolist() == ref, (wgt, best.cpu().tolist(), ref)
+        assert torch.equal(img.cpu(), torch.stack([fin[b * N + ref[b]] for b in range(B)]))
+        assert torch.equal(b1.cpu(), torch.stack([ps[b, ref[b]] for b in range(B)])) and torch.equal(b2.cpu(), torch.stack([ss[b, ref[b]] for b in range(B)]))
+    for rule, nr in (("max", "clip"), ("min", "niqe")):
+        best = ops.select_scores(None, dev(ps.reshape(-1)), N, rule=rule)[0]
+        assert best.cpu().tolist() == [O.select_ref(no_ref_list=ps[b].tolist(), no_ref=nr) for b in range(B)]
+
+
+def test_mc_mean(ops):
+    g = torch.Generator().manual_seed(6)
+    B, N, Hp, Wp, h, w = 2, 4, 24, 32, 21, 27
+    raw = torch.rand(B * N, 3, Hp, Wp, generator=g) * 1.4 - 0.2
+    tg = torch.rand(B, 3, h, w, generator=g)
+    for gm in (False, True):
+        got = ops.mc_mean(dev(raw), dev(tg), N, h, w, gm).cpu()
+        for b in range(B):
+            pr = raw[b * N:(b + 1) * N, :, :h, :w].permute(0, 2, 3, 1).numpy()
+            ref = O.mc_mean_ref(pr, tg[b].permute(1, 2, 0).numpy(), gm)
+            close(got[b].permute(1, 2, 0), torch.from_numpy(ref), 2e-6, 2e-6, f"mc mean gt_mean={gm}")
