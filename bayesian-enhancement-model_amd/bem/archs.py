@@ -63,13 +63,20 @@ class Decomp(nn.Module):
 
     def __init__(self, model="model4", wavelet_out=True, num_filters=32):
         super().__init__()
-        if model not in ("model1", "model4"):
-            raise NotImplementedError(f"decomp_model {model}: only model1 / model4 are built in this round")
+        if model not in ("model1", "model2", "model3", "model4"):
+            raise ValueError(f"Unknown decomp_model: {model}")
         self.model, self.wavelet_out = model, wavelet_out
         nf = num_filters
         self.conv_in = Conv2dK(32, nf, 3, padding=1)
-        self.branch_q1 = nn.Sequential(Conv2dK(nf, nf, 3, padding=1), nn.ReLU(inplace=True), Conv2dK(nf, nf, 3, padding=1))
-        self.branch_q2 = nn.Sequential(Conv2dK(nf, nf, 3, padding=1), nn.ReLU(inplace=True), Conv2dK(nf, nf, 3, padding=1))
+        if model == "model3":
+            # QD/model3.py:175-178 mini U-Net.  The wavelet-domain MyDecomp of the DDWavelet arch overrides forward() with the
+            # model1 / model4 op sequence, so there these three layers hold weights but are never applied (DDWavelet_arch.py:104-107).
+            self.down_conv = Conv2dK(nf, nf, 3, stride=2, padding=1)
+            self.mid_conv = Conv2dK(nf, nf, 3, padding=1)
+            self.up_conv = ConvT2x2(nf, nf)
+        d = 2 if model == "model2" else 1        # QD/model2.py:171-181: the second convolution of each branch is dilated
+        self.branch_q1 = nn.Sequential(Conv2dK(nf, nf, 3, padding=1), nn.ReLU(inplace=True), Conv2dK(nf, nf, 3, padding=d, dilation=d))
+        self.branch_q2 = nn.Sequential(Conv2dK(nf, nf, 3, padding=1), nn.ReLU(inplace=True), Conv2dK(nf, nf, 3, padding=d, dilation=d))
         self.cross_attn = _CrossAttnParams(nf)
         self.fuse = nn.Conv2d(nf * 2, nf, 1)
         self.conv_out = Conv2dK(nf, 32, 3, padding=1)
@@ -84,7 +91,10 @@ class Decomp(nn.Module):
         from safetensors.torch import load_file
         m = cls(model, wavelet_out)
         sd = load_file(os.path.join(_QD_DIR, f"{model}_999.safetensors"))
-        m.load_state_dict(sd, strict=False)      # strict=False: MyDecomp drops smooth_q* (DDWavelet_arch.py:138)
+        res = m.load_state_dict(sd, strict=False)      # strict=False: MyDecomp drops smooth_q* (DDWavelet_arch.py:138)
+        bad = [k for k in res.unexpected_keys if not k.startswith(("smooth_q1.", "smooth_q2."))]
+        if res.missing_keys or bad:
+            raise RuntimeError(f"frozen decomposition weights {model}_999: missing {res.missing_keys}, unexpected {bad}")
         m.eval()
         for p in m.parameters():
             p.requires_grad = False
@@ -121,8 +131,16 @@ class Decomp(nn.Module):
         P = self._prepared()
         d = ops.quat_dwt(x, c0)
         feat = self.conv_in(d)
-        f1 = self.branch_q1[2](self.branch_q1[0](feat, relu=True), res1=feat)
-        f2 = self.branch_q2[2](self.branch_q2[0](feat, relu=True), res1=feat)
+        if self.model == "model3" and not self.wavelet_out:
+            if self.training and torch.is_grad_enabled():
+                raise BemNativeError("Decomp model3: its attention dropout is active in train() mode (QD/model3.py:98,127); only the eval-mode "
+                                     "(identity) form is on the HIP path")
+            mid = self.mid_conv(self.down_conv(feat, relu=True), relu=True)
+            feat = ops.add(feat, self.up_conv._forward_nograd(mid))
+        dil = self.branch_q1[2].dilation[0]
+        b1, b2 = self.branch_q1[2], self.branch_q2[2]
+        f1 = ops.conv2d(self.branch_q1[0](feat, relu=True), b1.weight.detach(), b1.bias.detach(), pad=dil, dilation=dil, res1=feat)
+        f2 = ops.conv2d(self.branch_q2[0](feat, relu=True), b2.weight.detach(), b2.bias.detach(), pad=dil, dilation=dil, res1=feat)
         Wp, bias = ops.attn_fold(f1, f2, P["aw"], P["fw"], P["fb"])
         fused = ops.pw_gemm(f1, Wp, 32, x2=f2, in_mode=2, bias=bias)
         out = ops.conv2d(fused, P["co_w"], P["co_b"], pad=1)

@@ -32,7 +32,7 @@ class _Derived:
         self.d = {}
 
     def get(self, key, srcs, fn):
-        sig = (WEIGHT_EPOCH[0],) + tuple((t.data_ptr(), t._version) for t in srcs)
+        sig = (WEIGHT_EPOCH[0],) + tuple((t.data_ptr(), ops.tensor_version(t)) for t in srcs)
         hit = self.d.get(key)
         if hit is not None and hit[0] == sig:
             return hit[1]

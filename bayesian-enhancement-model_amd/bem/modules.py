@@ -30,7 +30,7 @@ class _Cache:
         self._d = {}
 
     def get(self, key, srcs, fn):
-        sig = (ops.WEIGHT_EPOCH[0],) + tuple((t.data_ptr(), t._version, t.device) for t in srcs)
+        sig = (ops.WEIGHT_EPOCH[0],) + tuple((t.data_ptr(), ops.tensor_version(t), t.device) for t in srcs)
         hit = self._d.get(key)
         if hit is not None and hit[0] == sig:
             return hit[1]
@@ -189,7 +189,7 @@ class Conv2dK(nn.Conv2d):
                 raise BemNativeError("Conv2dK: the training path covers the plain convolution (+ bias) only")
             return ag.Conv2dFn.apply(x, self.weight, self.bias, self, cin_slice)
         return ops.conv2d(x, self.weight.detach(), None if self.bias is None else self.bias.detach(),
-                          stride=self.stride[0], pad=self.padding[0], relu=relu, res1=res1, res2=res2, cin_slice=cin_slice)
+                          stride=self.stride[0], pad=self.padding[0], relu=relu, res1=res1, res2=res2, cin_slice=cin_slice, dilation=self.dilation[0])
 
 
 class ConvT2x2(nn.ConvTranspose2d):

@@ -78,6 +78,7 @@ SIGNATURES = {
     "bem_gate_proj_x6_f32": [P, P, I64, P, I64, P, I64, P, I64, P, P, I, I, I, I, I, P],
     "bem_conv3x3_x6_f32": [P, I64, P, P, P, P, P, I, I, I, I, I, I, P],
     "bem_conv4x4s2_x6_f32": [P, I64, P, P, P, P, P, I, I, I, I, I, I, P],
+    "bem_conv_taps_x6_f32": [P, I64, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "bem_gdmlp_fused_f32": [ctypes.POINTER(GdmlpArgs), P],
     "bem_pack_pw_weight_gate_f32": [P, P, I, I, I, P],
     "bem_dwconv3x3_f32": [P, P, I64, P, I64, P, I, I, I, I, I, P],

@@ -179,6 +179,12 @@ def bump_weight_epoch():
     WEIGHT_EPOCH[0] += 1
 
 
+def tensor_version(t) -> int:
+    """t._version for cache keys; tensors created under torch.inference_mode() (the reference's eval.py runs there) carry no
+    version counter and cannot be modified in place later, so a constant serves."""
+    return -1 if t.is_inference() else t._version
+
+
 def packed_elems(M: int, K: int, x6: bool = False) -> int:
     return int(lib().bem_pw_x6_packed_elems(M, K) if x6 else lib().bem_pw_packed_elems(M, K))
 
@@ -383,7 +389,7 @@ USE_CONV_MFMA = __import__("os").environ.get("BEM_CONV_MFMA", "1") != "0"
 
 
 def _packed_conv_weight(w):
-    key = (w.data_ptr(), w._version, tuple(w.shape), WEIGHT_EPOCH[0])
+    key = (w.data_ptr(), tensor_version(w), tuple(w.shape), WEIGHT_EPOCH[0])
     hit = _CONV_PACK.get(key)
     if hit is None:
         if len(_CONV_PACK) > 256:
@@ -401,7 +407,7 @@ USE_CONV4_X6 = __import__("os").environ.get("BEM_CONV4_X6", "0") != "0"
 
 
 def _packed_conv_weight_x6(w):
-    key = (w.data_ptr(), w._version, tuple(w.shape), WEIGHT_EPOCH[0])
+    key = (w.data_ptr(), tensor_version(w), tuple(w.shape), WEIGHT_EPOCH[0])
     hit = _CONV_PACK_X6.get(key)
     if hit is None:
         if len(_CONV_PACK_X6) > 256:
@@ -412,9 +418,10 @@ def _packed_conv_weight_x6(w):
     return hit[1]
 
 
-def conv2d(x, w, bias=None, stride=1, pad=1, relu=False, res1=None, res2=None, cin_slice=None):
+def conv2d(x, w, bias=None, stride=1, pad=1, relu=False, res1=None, res2=None, cin_slice=None, dilation=1):
     """Dense conv.  ``cin_slice=(c0, Cin)`` convolves channels [c0, c0+Cin) of a wider contiguous x.
-    Runs as an implicit GEMM on the matrix cores (Cout <= 160), else on the direct VALU kernel."""
+    Runs as an implicit GEMM on the matrix cores (Cout <= 160), else on the direct VALU kernel.
+    dilation 2 (3x3, pad 2) and 3x3 stride 2 exist in the shifted-tap form only (QD model2 / model3)."""
     _chk(x, "x"); _chk(w, "w"); _chk(bias, "bias", optional=True)
     _chk(res1, "res1", optional=True); _chk(res2, "res2", optional=True)
     B, Ct, H, W = x.shape
@@ -426,8 +433,18 @@ def conv2d(x, w, bias=None, stride=1, pad=1, relu=False, res1=None, res2=None, c
             raise ValueError("conv2d: channel slice out of range")
     elif Ct != Cin:
         raise ValueError(f"conv2d: input has {Ct} channels, weight expects {Cin}")
-    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    Ho, Wo = (H + 2 * pad - dilation * (KH - 1) - 1) // stride + 1, (W + 2 * pad - dilation * (KW - 1) - 1) // stride + 1
     out = torch.empty(B, Cout, Ho, Wo, device=x.device, dtype=x.dtype)
+    if dilation != 1 or (KH, KW, stride) == (3, 3, 2):
+        if (KH, KW) != (3, 3) or pad != dilation or not USE_X6 or Wo % 2 or Cin % 8 or (c0 * H * W) % 2:
+            raise ValueError("conv2d: dilated / strided 3x3 convolutions run in the tap form only (pad = dilation, even output width, Cin % 8 == 0)")
+        for n, r in (("res1", res1), ("res2", res2)):
+            if r is not None and r.shape != out.shape:
+                raise ValueError(f"conv2d: {n} shape")
+        xp_ = ctypes.c_void_p(x.data_ptr() + 4 * c0 * H * W)
+        check(lib().bem_conv_taps_x6_f32(xp_, Ct * H * W, _p(_packed_conv_weight_x6(w)), _p(bias), _p(res1), _p(res2), _p(out), B, Cin, H, W, Cout, 3, stride,
+                                         dilation, int(relu), _stream()), "conv_taps_x6")
+        return out
     for n, r in (("res1", res1), ("res2", res2)):
         if r is not None and r.shape != out.shape:
             raise ValueError(f"conv2d: {n} shape")

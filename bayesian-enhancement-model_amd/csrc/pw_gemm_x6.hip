@@ -754,7 +754,7 @@ namespace {
 struct CvX {
     const float* x; int64_t x_bs;
     const u32x4* Wp; const float* bias; const float* res1; const float* res2; float* out;
-    int Cin, H, W, Ho, Wo, Cout, KB, MT, relu, pad;
+    int Cin, H, W, Ho, Wo, Cout, KB, MT, relu, pad, dil;
 };
 
 template <int MTW, int KH, int KW, int S>
@@ -785,7 +785,7 @@ __global__ __launch_bounds__(256, 2) void conv_taps_x6_kernel(CvX k) {
     auto load_x = [&](int s, float (&dst)[8][NSUB], float (&mk)[NSUB]) {
         const int kb = min(s / NTAP, k.KB - 1), tap = s - (s / NTAP) * NTAP;
         const int ky = tap / KW, kx = tap - ky * KW;
-        const int yy = yi0 + ky, x0 = xi0 + kx, x1 = x0 + S;
+        const int yy = yi0 + ky * k.dil, x0 = xi0 + kx * k.dil, x1 = x0 + S;
         const bool rowok = live && yy >= 0 && yy < k.H;
         mk[0] = (rowok && x0 >= 0 && x0 < k.W) ? 1.f : 0.f;
         mk[1] = (rowok && x1 >= 0 && x1 < k.W) ? 1.f : 0.f;
@@ -890,10 +890,13 @@ __global__ __launch_bounds__(256, 2) void conv_taps_x6_kernel(CvX k) {
 }  // namespace
 
 static int conv_taps_launch(const float* x, int64_t x_bstride, const float* Wp, const float* bias, const float* res1, const float* res2,
-                            float* out, int B, int Cin, int H, int W, int Cout, int KH, int stride, int relu, void* stream, const char* what) {
+                            float* out, int B, int Cin, int H, int W, int Cout, int KH, int stride, int dil, int relu, void* stream, const char* what) {
     BEM_REQUIRE(x && Wp && out, "%s: null tensor", what);
     BEM_REQUIRE(B >= 0 && B <= 65535 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "%s: bad shape", what);
-    const int Ho = (H + 2 - KH) / stride + 1, Wo = (W + 2 - KH) / stride + 1;
+    BEM_REQUIRE((KH == 3 && stride == 1 && (dil == 1 || dil == 2)) || (KH == 3 && stride == 2 && dil == 1) || (KH == 4 && stride == 2 && dil == 1),
+                "%s: supported forms are 3x3 s1 (dilation 1 / 2, padding = dilation), 3x3 s2 p1 and 4x4 s2 p1", what);
+    const int pad = dil;                                        // "same" padding of the dilated 3x3; 1 for the others
+    const int Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
     BEM_REQUIRE(Ho > 0 && Wo > 0 && Wo % 2 == 0 && Cin % 8 == 0 && H * W >= 2, "%s: needs an even output width and Cin %% 8 == 0 (got Wo=%d Cin=%d)", what, Wo, Cin);
     BEM_REQUIRE(((uintptr_t)Wp & 15) == 0 && (((uintptr_t)out | (uintptr_t)(res1 ? res1 : out) | (uintptr_t)(res2 ? res2 : out)) & 7) == 0,
                 "%s: alignment (packed weights 16 bytes, out / residuals 8 bytes)", what);
@@ -901,13 +904,16 @@ static int conv_taps_launch(const float* x, int64_t x_bstride, const float* Wp, 
     if (B == 0) return BEM_OK;
     CvX k;
     k.x = x; k.x_bs = x_bstride; k.Wp = reinterpret_cast<const u32x4*>(Wp); k.bias = bias; k.res1 = res1; k.res2 = res2; k.out = out;
-    k.Cin = Cin; k.H = H; k.W = W; k.Ho = Ho; k.Wo = Wo; k.Cout = Cout; k.KB = cdiv(Cin, 16); k.MT = cdiv(Cout, 32); k.relu = relu; k.pad = 1;
+    k.Cin = Cin; k.H = H; k.W = W; k.Ho = Ho; k.Wo = Wo; k.Cout = Cout; k.KB = cdiv(Cin, 16); k.MT = cdiv(Cout, 32); k.relu = relu; k.pad = pad; k.dil = dil;
     const int mtw = k.MT == 1 ? 1 : 2;
     dim3 grid(cdiv(Ho * Wo, 256), cdiv(k.MT, mtw), B);
     hipStream_t s = (hipStream_t)stream;
-    if (KH == 3) {
+    if (KH == 3 && stride == 1) {
         if (mtw == 1) conv_taps_x6_kernel<1, 3, 3, 1><<<grid, 256, 0, s>>>(k);
         else conv_taps_x6_kernel<2, 3, 3, 1><<<grid, 256, 0, s>>>(k);
+    } else if (KH == 3) {
+        if (mtw == 1) conv_taps_x6_kernel<1, 3, 3, 2><<<grid, 256, 0, s>>>(k);
+        else conv_taps_x6_kernel<2, 3, 3, 2><<<grid, 256, 0, s>>>(k);
     } else {
         if (mtw == 1) conv_taps_x6_kernel<1, 4, 4, 2><<<grid, 256, 0, s>>>(k);
         else conv_taps_x6_kernel<2, 4, 4, 2><<<grid, 256, 0, s>>>(k);
@@ -917,12 +923,17 @@ static int conv_taps_launch(const float* x, int64_t x_bstride, const float* Wp, 
 
 extern "C" int bem_conv3x3_x6_f32(const float* x, int64_t x_bstride, const float* Wp, const float* bias, const float* res1,
                                   const float* res2, float* out, int B, int Cin, int H, int W, int Cout, int relu, void* stream) {
-    return conv_taps_launch(x, x_bstride, Wp, bias, res1, res2, out, B, Cin, H, W, Cout, 3, 1, relu, stream, "conv3x3_x6");
+    return conv_taps_launch(x, x_bstride, Wp, bias, res1, res2, out, B, Cin, H, W, Cout, 3, 1, 1, relu, stream, "conv3x3_x6");
 }
 
 extern "C" int bem_conv4x4s2_x6_f32(const float* x, int64_t x_bstride, const float* Wp, const float* bias, const float* res1,
                                     const float* res2, float* out, int B, int Cin, int H, int W, int Cout, int relu, void* stream) {
-    return conv_taps_launch(x, x_bstride, Wp, bias, res1, res2, out, B, Cin, H, W, Cout, 4, 2, relu, stream, "conv4x4s2_x6");
+    return conv_taps_launch(x, x_bstride, Wp, bias, res1, res2, out, B, Cin, H, W, Cout, 4, 2, 1, relu, stream, "conv4x4s2_x6");
+}
+
+extern "C" int bem_conv_taps_x6_f32(const float* x, int64_t x_bstride, const float* Wp, const float* bias, const float* res1, const float* res2,
+                                    float* out, int B, int Cin, int H, int W, int Cout, int K, int stride, int dilation, int relu, void* stream) {
+    return conv_taps_launch(x, x_bstride, Wp, bias, res1, res2, out, B, Cin, H, W, Cout, K, stride, dilation, relu, stream, "conv_taps_x6");
 }
 
 // ================================================================================================

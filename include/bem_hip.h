@@ -188,6 +188,12 @@ int bem_conv3x3_x6_f32(const float* x, int64_t x_bstride, const float* Wp, const
 int bem_conv4x4s2_x6_f32(const float* x, int64_t x_bstride, const float* Wp, const float* bias, const float* res1,
                          const float* res2, float* out, int B, int Cin, int H, int W, int Cout, int relu, void* stream);
 
+/* The general entry of the tap form: K x K taps with `stride` and `dilation`; supported: 3x3 s1 d1 (pad 1), 3x3 s1 d2 (pad 2: the dilated
+ * branch convolutions of QD/model2.py:171-181), 3x3 s2 d1 (pad 1: down_conv of QD/model3.py:176), 4x4 s2 d1 (pad 1).  Wp as above
+ * (K*K tap matrices, tap = ky*K + kx). */
+int bem_conv_taps_x6_f32(const float* x, int64_t x_bstride, const float* Wp, const float* bias, const float* res1, const float* res2,
+                         float* out, int B, int Cin, int H, int W, int Cout, int K, int stride, int dilation, int relu, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Quaternion / Haar primitives (basicsr/QD/model4.py:7-37,216-232; QD/quaternion.py:3-17).
  * ------------------------------------------------------------------------------------------- */

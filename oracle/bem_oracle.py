@@ -282,28 +282,36 @@ def cross_attention_ref(sd: SD, pre: str, f1, f2):
     return o1, o2
 
 
-def decomp_trunk_ref(sd: SD, pre: str, img):
+def decomp_trunk_ref(sd: SD, pre: str, img, model=None, mini_unet=True):
     """Shared trunk: quaternion stack -> DWT -> convs -> cross attention -> fuse -> conv_out +
-    sharpening.  Returns the 32-channel wavelet-domain map (before IWT / index split)."""
-    c3 = lambda n, t: F.conv2d(t, sd[pre + n + ".weight"], sd[pre + n + ".bias"], padding=1)
+    sharpening.  Returns the 32-channel wavelet-domain map (before IWT / index split).
+    model: None / 'model1' / 'model4' (QD/model4.py:234-256) | 'model2' (second branch convs dilated by 2, QD/model2.py:171-181) |
+    'model3' (mini U-Net in front of the branches, QD/model3.py:245-258; recognised by its down_conv weights too).  Dropout layers
+    of model3 are identities in eval mode."""
+    c3 = lambda n, t, **kw: F.conv2d(t, sd[pre + n + ".weight"], sd[pre + n + ".bias"], **({"padding": 1} | kw))
     feat = c3("conv_in", dwt_ref(quaternion_stack_ref(img)))
-    f1 = c3("branch_q1.2", F.relu(c3("branch_q1.0", feat))) + feat
-    f2 = c3("branch_q2.2", F.relu(c3("branch_q2.0", feat))) + feat
+    if mini_unet and (model == "model3" or (model is None and pre + "down_conv.weight" in sd)):
+        mid = F.relu(c3("mid_conv", F.relu(c3("down_conv", feat, stride=2))))
+        feat = feat + F.conv_transpose2d(mid, sd[pre + "up_conv.weight"], sd[pre + "up_conv.bias"], stride=2)
+    dil = dict(padding=2, dilation=2) if model == "model2" else {}
+    f1 = c3("branch_q1.2", F.relu(c3("branch_q1.0", feat)), **dil) + feat
+    f2 = c3("branch_q2.2", F.relu(c3("branch_q2.0", feat)), **dil) + feat
     f1, f2 = cross_attention_ref(sd, pre + "cross_attn.", f1, f2)
     fused = F.conv2d(torch.cat([f1, f2], 1), sd[pre + "fuse.weight"], sd[pre + "fuse.bias"])
     out = c3("conv_out", fused)
     return out + c3("sharpening", out)
 
 
-def decomp_wavelet_ref(sd: SD, pre: str, img):
-    """MyDecomp.forward (DecompDualBranchDDWavelet_arch.py:80-132): even channels -> Q1_w, odd -> Q2_w."""
-    out = decomp_trunk_ref(sd, pre, img)
+def decomp_wavelet_ref(sd: SD, pre: str, img, model=None):
+    """MyDecomp.forward (DecompDualBranchDDWavelet_arch.py:80-132): even channels -> Q1_w, odd -> Q2_w.  MyDecomp overrides the base
+    class's forward with the model1 / model4 op sequence: for model3 the mini U-Net weights are loaded but never applied (:104-107)."""
+    out = decomp_trunk_ref(sd, pre, img, model, mini_unet=False)
     return out[:, 0::2], out[:, 1::2]
 
 
-def decomp_full_ref(sd: SD, pre: str, img):
-    """Decomp.forward of model1 (no smoothing) / model4 (PostSmooth when smooth_q* weights exist)."""
-    out = iwt_ref(decomp_trunk_ref(sd, pre, img))
+def decomp_full_ref(sd: SD, pre: str, img, model=None):
+    """Decomp.forward of model1 / model2 / model3 (no smoothing) / model4 (PostSmooth when smooth_q* weights exist)."""
+    out = iwt_ref(decomp_trunk_ref(sd, pre, img, model))
     q1, q2 = out[:, [0, 2, 4, 6]], out[:, [1, 3, 5, 7]]
     if pre + "smooth_q1.conv.weight" in sd:
         sm = lambda n, t: t + F.relu(F.conv2d(t, sd[pre + n + ".conv.weight"], sd[pre + n + ".conv.bias"], padding=1, groups=4))
@@ -322,11 +330,11 @@ def _levels(sd: SD, pre: str) -> int:
     return n
 
 
-def ddwavelet_ref(sd: SD, x, scan=selective_scan_ref, pre: str = ""):
+def ddwavelet_ref(sd: SD, x, scan=selective_scan_ref, pre: str = "", decomp_model=None):
     """DecompDualBranchDDWavelet.forward (DecompDualBranchDDWavelet_arch.py:301-369). Returns final_out."""
     img, cond = x[:, 0:3], x[:, 3:6]
-    q1i, q2i = decomp_wavelet_ref(sd, pre + "decomp.", img)
-    q1c, q2c = decomp_wavelet_ref(sd, pre + "decomp.", cond)
+    q1i, q2i = decomp_wavelet_ref(sd, pre + "decomp.", img, decomp_model)
+    q1c, q2c = decomp_wavelet_ref(sd, pre + "decomp.", cond, decomp_model)
     nl = _levels(sd, pre + "down_layers_Q1.") + 1
     feats, skips = {}, {}
     for br, q in (("Q1", torch.cat([q1i, q1c], 1)), ("Q2", torch.cat([q2i, q2c], 1))):
@@ -351,10 +359,10 @@ def ddwavelet_ref(sd: SD, x, scan=selective_scan_ref, pre: str = ""):
     return hamilton_ref(outs[0], outs[1])[:, 1:]
 
 
-def singlebranch_ref(sd: SD, x, scan=selective_scan_ref, pre: str = ""):
+def singlebranch_ref(sd: SD, x, scan=selective_scan_ref, pre: str = "", decomp_model=None):
     """DecompSingleBranch.forward (DecompSingleBranch_arch.py:195-237). Returns final_out."""
     img, cond = x[:, :3], x[:, 3:]
-    q1, q2 = decomp_full_ref(sd, pre + "decomp.", img)
+    q1, q2 = decomp_full_ref(sd, pre + "decomp.", img, decomp_model)
     f = F.conv2d(torch.cat([q1, q2, cond], 1), sd[pre + "first_conv.weight"], sd[pre + "first_conv.bias"], padding=1)
     nl = _levels(sd, pre + "down_layers.") + 1
     sk = []

@@ -336,3 +336,36 @@ def test_eval_driver_cli(tmp_path):
     txt = open(os.path.join(out["result_dir"], "result.txt")).read()
     assert "Best_PSNR" in txt and "Best_SSIM" in txt and "MC_PSNR" in txt
     assert len(out["psnr"]) == 2 and all(5 < p < 100 for p in out["psnr"]) and all(0 < s <= 1 for s in out["ssim"])
+
+
+@pytest.mark.parametrize("tag", ["model2", "model3"])
+def test_decomp_model2_model3_golden(tag):
+    """QD model2 (dilated branch convolutions) / model3 (mini U-Net, eval mode) with the shipped weights against the outputs recorded
+    from the reference (g5_decomp23.npz): the wavelet-domain maps the DDWavelet arch consumes and the full-resolution Q1 / Q2."""
+    import bem.archs as A
+    g = load_golden("g5_decomp23")
+    img = g["img"].cuda()
+    dw = A.Decomp.from_shipped(tag, wavelet_out=True).cuda()
+    out = dw(img).cpu()
+    close(out[:, :16], g[f"q1w_{tag}"], 2e-4, 2e-5, tag + " Q1_w"); close(out[:, 16:], g[f"q2w_{tag}"], 2e-4, 2e-5, tag + " Q2_w")
+    df = A.Decomp.from_shipped(tag, wavelet_out=False).cuda()
+    q = df(img).cpu()
+    close(q[:, :4], g[f"q1_{tag}"], 2e-4, 2e-5, tag + " Q1"); close(q[:, 4:], g[f"q2_{tag}"], 2e-4, 2e-5, tag + " Q2")
+
+
+@pytest.mark.parametrize("yml", ["DecompDualBranch2DDWavelet_4.yml", "DecompSingleBranch_1.yml"])
+@pytest.mark.parametrize("dm", ["model2", "model3"])
+def test_archs_build_and_run_with_every_decomp_model(yml, dm):
+    """Every shipped Decomp* option file differs only in network_g.type and decomp_model: the *_2 / *_3 variants build
+    and run, and agree with the oracle evaluated with the same weights."""
+    from basicsr.archs import build_network
+    from basicsr.utils.options import parse
+    opt = parse(os.path.join(PKG, "Options", yml), is_train=False)
+    ng = dict(opt["network_g"], decomp_model=dm, n_feat=8, num_blocks=[1, 1, 1])
+    torch.manual_seed(3)
+    net = build_network(ng).cuda().eval()
+    x = torch.rand(1, 6, 32, 32, generator=torch.Generator().manual_seed(4))
+    out = net(x.cuda())[-1].cpu()
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    ref = (O.ddwavelet_ref if "Wavelet" in yml else O.singlebranch_ref)(sd, x, O.selective_scan_c, **({"decomp_model": dm}))
+    close(out, ref, 2e-3, 1e-4, f"{yml} {dm}")

@@ -108,3 +108,31 @@ def test_g9_sibling_archs(tag, fn, dm):
     sd = dict(g["sd"])
     sd.update(qd_state_dict(dm))
     close(fn(sd, g["x"], O.selective_scan_c), g["out"], rtol=1e-3, atol=2e-5)
+
+
+def test_g5_decomp_model2_model3():
+    """QD model2 (dilated branch convs) and model3 (mini U-Net; eval mode) with the shipped weights: wavelet-domain and full maps
+    recorded from the reference (tests/golden/make_golden_r2.py)."""
+    g = load_golden("g5_decomp23")
+    for tag in ("model2", "model3"):
+        sd = qd_state_dict(tag, prefix="")
+        q1w, q2w = O.decomp_wavelet_ref(sd, "", g["img"], tag)
+        close(q1w, g[f"q1w_{tag}"], 1e-5, 1e-6); close(q2w, g[f"q2w_{tag}"], 1e-5, 1e-6)
+        q1, q2 = O.decomp_full_ref(sd, "", g["img"], tag)
+        close(q1, g[f"q1_{tag}"], 1e-5, 1e-6); close(q2, g[f"q2_{tag}"], 1e-5, 1e-6)
+
+
+def test_g10_training_step():
+    """The oracle's restatement of image_enhancer_model.py:165-216 (L1, clip 1.0, AdamW 2e-4 / 1e-4) for two steps against the
+    reference's own modules and torch optimizer: per-step loss and gradient norm, every step-1 gradient, every parameter after step 2."""
+    g = load_golden("g10_train")
+    g6 = load_golden("g6_ddw")
+    sd = {**g6["sd"], **qd_state_dict("model4")}
+    r = O.train_step_ref(sd, g["lq"], g["gt"], g["gt_down"], steps=2, lr=2e-4, weight_decay=1e-4, max_grad_norm=1.0)
+    assert np.allclose(r["loss"], g["loss"].numpy() if hasattr(g["loss"], "numpy") else g["loss"], rtol=0, atol=1e-7)
+    assert np.allclose(r["grad_norm"], np.asarray(g["grad_norm"]), rtol=1e-6)
+    assert set(r["grads"]) == set(g["grads"]) == set(g["params"])
+    for k, v in g["grads"].items():
+        close(r["grads"][k], v, 1e-5, 1e-9)
+    for k, v in g["params"].items():
+        close(r["params"][k], v, 0, 1e-6)      # two AdamW steps of 2e-4; Adam amplifies rounding-level gradient differences near g = 0
