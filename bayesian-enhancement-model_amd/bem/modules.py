@@ -44,6 +44,7 @@ class _Cache:
 # pixel per lane -- 189 vs 232 img/s end to end -- so off by default
 GATE_PROJ = __import__("os").environ.get("BEM_GATE_PROJ", "0") != "0"
 SCAN_RM = os.environ.get("BEM_SCAN_RM", "1") != "0"          # row-major SS2D scan (no transposes of xc / y1) where the plane size allows
+PI_GATE = os.environ.get("BEM_PI_GATE", "1") != "0"          # project_in + depthwise 3x3 + gate in one kernel where it applies (C <= 48)
 FUSE_GDMLP = os.environ.get("BEM_FUSE_GDMLP", "0") != "0"    # 0: unfused three-kernel gdMlp (kept for A/B checks)
 
 
@@ -370,6 +371,19 @@ class gdMlp(nn.Module):
         if FUSE_GDMLP and ops.gdmlp_fused_supported(C, Hd) and _has_bias(self.project_in):
             Wpi, bpi, dww, dwb, Wpo, bpo = self._fused_params(B)
             return ops.gdmlp_fused(x, norm.weight.detach(), norm.bias.detach(), norm.eps, Wpi, bpi, dww, dwb, Wpo, bpo, Hd)
+        if PI_GATE and isinstance(self.project_in, PwConv2d) and isinstance(self.dwconv, DwConv2d) and ops.pi_gate_supported(C, Hd):
+            # the 2Hd-channel project_in output lives only in LDS (bem_pi_gate_x6_f32); deterministic weights, C <= 48
+            pi, dw = self.project_in, self.dwconv
+
+            def prep():
+                perm = ops.gate_order(Hd, pi.weight.device)
+                return (ops.pack_pw_weight(pi.weight.detach().reshape(2 * Hd, C)[perm].contiguous(), x6=True),
+                        None if pi.bias is None else pi.bias.detach()[perm].contiguous())
+            Wg, bg = self._cache.get("pi_gate", [t for t in (pi.weight, pi.bias) if t is not None], prep)
+            w, bw = dw.dw_weights(B)
+            g = ops.pi_gate(x, norm.weight.detach(), norm.bias.detach(), norm.eps, Wg, bg, w, bw, Hd)
+            Wp, b = self.project_out.gemm_weights(B)
+            return ops.pw_gemm(g, Wp, _out_features(self.project_out), bias=b, res=x)
         Wp, b = self.project_in.gemm_weights(B)
         if GATE_PROJ and ops.USE_X6:
             # depthwise 3x3 + gate inside the loader of project_out: the gated Hd-channel tensor never exists in HBM

@@ -308,6 +308,37 @@ def gate_proj(h, dww, dwb, Wp, M, bias=None, res=None):
     return out
 
 
+def gate_order(Hd, device):
+    """row permutation of a (2Hd, ...) project_in parameter into the gate order of bem_pi_gate_x6_f32."""
+    j = torch.arange(Hd // 16, device=device)[:, None]
+    r = torch.arange(16, device=device)[None, :]
+    return torch.cat([16 * j + r, Hd + 16 * j + r], 1).reshape(-1)
+
+
+def pi_gate_supported(C, Hd):
+    return USE_X6 and C <= 48 and Hd % 16 == 0
+
+
+def pi_gate(x, ln_w, ln_b, ln_eps, Wp_gate, bias_gate, dww, dwb, Hd):
+    """GELU(h1) * h2 with [h1; h2] = dw3x3(project_in(LayerNorm2d(x))) in one kernel (bem_pi_gate_x6_f32).
+    Wp_gate = pack_pw_weight(W_i[gate_order(Hd)], x6=True), bias_gate = b_i[gate_order(Hd)]; dww (2Hd,1,3,3), dwb (2Hd) | None."""
+    _chk(x, "x"); _chk(ln_w, "ln_w"); _chk(ln_b, "ln_b"); _chk(Wp_gate, "Wp_gate"); _chk(bias_gate, "bias_gate", optional=True)
+    _chk(dww, "dww"); _chk(dwb, "dwb", optional=True)
+    B, C, H, W = x.shape
+    if not pi_gate_supported(C, Hd):
+        raise ValueError(f"pi_gate: C = {C} (<= 48) / Hd = {Hd} (% 16) not supported")
+    if ln_w.numel() != C or ln_b.numel() != C or dww.numel() != 2 * Hd * 9 or (dwb is not None and dwb.numel() != 2 * Hd) \
+            or (bias_gate is not None and bias_gate.numel() != 2 * Hd):
+        raise ValueError("pi_gate: parameter shapes")
+    if Wp_gate.dim() != 2 or Wp_gate.shape[0] != 1 or Wp_gate.shape[1] != packed_elems(2 * Hd, C, True) \
+            or getattr(Wp_gate, "_bem_mk", (2 * Hd, C)) != (2 * Hd, C):
+        raise ValueError(f"pi_gate: packed weight {tuple(Wp_gate.shape)} does not match M={2 * Hd} K={C} (x6 format, one weight set)")
+    g = torch.empty(B, Hd, H, W, device=x.device, dtype=x.dtype)
+    check(lib().bem_pi_gate_x6_f32(_p(x), _p(ln_w), _p(ln_b), float(ln_eps), _p(Wp_gate), _p(bias_gate), _p(dww), _p(dwb), _p(g),
+                                   B, C, Hd, H, W, _stream()), "pi_gate")
+    return g
+
+
 def pack_pw_weight_gate(W, Hd):
     """project_in weight (2Hd,K) or (nsets,2Hd,K) -> packed with gate rows regrouped per 16 channels."""
     _chk(W, "W")

@@ -1,0 +1,220 @@
+// gdMlp front half in one kernel:  g = GELU(h1) * h2,  [h1; h2] = dwconv3x3(project_in(LayerNorm2d(x))) + biases
+// (reference: basicsr/vmamba/models/vmamba.py:116-131 gdMlp.forward up to the gate, with the block's norm2 :1330).
+//
+// Why: as three kernels the 8C-channel tensor t = project_in(LN(x)) is written once and read once (level 0 of the bench:
+// 1.34 GB each way, 2/3 of the block's HBM traffic).  Here t only ever exists as 32-channel slices of one pixel tile in LDS.
+//
+// Mapping:
+//   * workgroup = 4 waves = one 8 x 32 pixel tile of one image; its 10 x 34 halo is 340 pixels = 11 MFMA pixel blocks of 32.
+//     Wave w owns halo blocks w, w + 4, w + 8 and keeps their LayerNorm-ed input, already split into bf16 limbs, in
+//     registers for the whole kernel (x is read once per tile; the halo overlap comes from L2).
+//   * the 2*Hd project_in rows are packed by the host in "gate order": M-tile j = [16 h1 rows 16j..16j+15 | the 16 h2 rows
+//     Hd + 16j ..], so that one 32-row MFMA tile yields both gate inputs of 16 output channels.
+//   * per chunk j:  phase A  t(32 rows x 340 halo pixels) = W_j * x on the bf16 matrix cores (exact 3-limb products, see
+//     pw_gemm_x6.hip) + bias, forced to zero outside the image (the depthwise conv zero-pads t, not x), into LDS;
+//     phase B  wave w takes output rows 2w, 2w+1 (lanes 0-31 / 32-63), lane = column: 3x3 window from LDS, depthwise
+//     weights are wave-uniform (scalar loads), erf-form GELU gate, one 128-byte store per half-wave and channel.
+//     Measured (64 x 40 x 128 x 128, Hd 160): 650 us against 358 + 363 us for project_in + depthwise gate as two kernels, with
+//     2.7 GB less HBM traffic.  The phases do not overlap in practice: with either phase disabled the time drops by that
+//     phase's full share (prologue 115 us, phase A 207 us, phase B 424 us; scripts/pig_time.py), and delaying every second
+//     workgroup by one phase changes nothing.  (A packed-math variant -- float2 (h1, h2) LDS layout, two pixels per lane, v_pk_fma -- has 40 % fewer VALU and LDS
+//     instructions and was slower, 730 vs 650 us: the kernel is bound by latency at two waves per SIMD, not by issue.)
+//   * two workgroups share a CU (45 KB LDS each), so one's MFMA phase overlaps the other's VALU/LDS phase.
+#include "bem_common.h"
+#include "x6_common.h"
+#include <stdlib.h>
+
+namespace {
+
+struct PgX {
+    const float* x; const float* ln_w; const float* ln_b; float ln_eps;
+    const u32x4* Wp;            // gate-order project_in weights, x6-packed: [NCH][KB][3][64]
+    int C, Hd, H, W, KB, NCH, tx, dbg;
+};
+
+constexpr int PG_TH = 8, PG_TW = 32, PG_HW = PG_TW + 2, PG_NPH = (PG_TH + 2) * PG_HW, PG_NPB = (PG_NPH + 31) / 32;
+constexpr int PG_BPW = (PG_NPB + 3) / 4, PG_TS = PG_NPB * 32;
+
+// dww / dwb / bpi / g are separate __restrict__ arguments (not struct fields) so that the compiler knows the stores to g cannot
+// touch them: the wave-uniform depthwise parameters then come in through scalar loads instead of per-lane vector loads.
+template <int KBM>
+__global__ __launch_bounds__(256, 2) void pi_gate_x6_kernel(PgX k, const float* __restrict__ dww, const float* __restrict__ dwb,
+                                                            const float* __restrict__ bpi, float bmul, float dbmul, float* __restrict__ g) {
+    __shared__ float T[32 * PG_TS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kh = lane >> 5, n = lane & 31;
+    const int b = blockIdx.z;
+    const int tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int tyi = tile / k.tx, txi = tile - tyi * k.tx;
+    const int y0 = tyi * PG_TH, x0 = txi * PG_TW;
+    const int L = k.H * k.W;
+    const float* xb = k.x + (int64_t)b * k.C * L;
+
+    // ---- this wave's halo pixel blocks: load, LayerNorm over channels, split into limbs
+    float lnw[KBM][8], lnb[KBM][8];
+#pragma unroll
+    for (int kb = 0; kb < KBM; ++kb)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ch = 16 * kb + 8 * kh + e;
+            const float on = ch < k.C ? 1.f : 0.f;
+            lnw[kb][e] = k.ln_w[min(ch, k.C - 1)] * on;
+            lnb[kb][e] = k.ln_b[min(ch, k.C - 1)] * on;
+        }
+    u32x4 xl[PG_BPW][KBM][3];
+    float msk[PG_BPW];
+    int hpo[PG_BPW];
+#pragma unroll
+    for (int i = 0; i < PG_BPW; ++i) {
+        const int hp = min((wave + 4 * i) * 32 + n, PG_TS - 1);
+        hpo[i] = hp;
+        const int hy = hp / PG_HW, hx = hp - hy * PG_HW;
+        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        const bool in = hp < PG_NPH && gy >= 0 && gy < k.H && gx >= 0 && gx < k.W;
+        msk[i] = in ? 1.f : 0.f;
+        const int off = min(max(gy, 0), k.H - 1) * k.W + min(max(gx, 0), k.W - 1);
+        float xr[KBM][8];
+#pragma unroll
+        for (int kb = 0; kb < KBM; ++kb)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ch = 16 * kb + 8 * kh + e;
+                const float v = xb[(int64_t)min(ch, k.C - 1) * L + off];
+                xr[kb][e] = ch < k.C ? v : 0.f;
+            }
+        const float inv = 1.f / (float)k.C;
+        float s = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < KBM; ++kb)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += xr[kb][e];
+        s += __shfl_xor(s, 32, 64);
+        const float mean = s * inv;
+        float q = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < KBM; ++kb)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = (16 * kb + 8 * kh + e < k.C) ? xr[kb][e] - mean : 0.f;
+                q = fmaf(d, d, q);
+            }
+        q += __shfl_xor(q, 32, 64);
+        const float rstd = 1.f / sqrtf(q * inv + k.ln_eps);
+#pragma unroll
+        for (int kb = 0; kb < KBM; ++kb) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (xr[kb][e] - mean) * rstd * lnw[kb][e] + lnb[kb][e];
+            split8(v, xl[i][kb][0], xl[i][kb][1], xl[i][kb][2]);
+        }
+    }
+
+    const u32x4* wbase = k.Wp + lane;
+    const int64_t ch_stride = (int64_t)k.KB * 3 * 64;
+    u32x4 wc[KBM][3];
+    float4 bq[4];
+    auto load_w = [&](int j) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(bpi + 32 * j + 8 * q + 4 * kh);
+            bq[q] = make_float4(v.x * bmul, v.y * bmul, v.z * bmul, v.w * bmul);
+        }
+#pragma unroll
+        for (int kb = 0; kb < KBM; ++kb) {
+            const uint32_t mk = kb < k.KB ? 0xffffffffu : 0u;
+            const u32x4* wp = wbase + (int64_t)j * ch_stride + (int64_t)min(kb, k.KB - 1) * 3 * 64;
+#pragma unroll
+            for (int li = 0; li < 3; ++li) {
+                const u32x4 w = wp[li * 64];
+                wc[kb][li] = u32x4{w[0] & mk, w[1] & mk, w[2] & mk, w[3] & mk};
+            }
+        }
+    };
+    load_w(0);
+
+    // phase-B geometry: output pixel (ry, n) of the tile; its window starts at halo (ry, n)
+    const int ry = 2 * wave + kh;
+    const int oy = y0 + ry, ox = x0 + n;
+    const bool ost = oy < k.H && ox < k.W;
+    const int wbase_lds = ry * PG_HW + n;
+    float* gb = g + (int64_t)b * k.Hd * L + (int64_t)min(oy, k.H - 1) * k.W + min(ox, k.W - 1);
+
+    for (int j = 0; j < k.NCH; ++j) {
+        // ---- phase A
+#pragma unroll
+        for (int i = 0; i < PG_BPW; ++i) {
+            if (wave + 4 * i < PG_NPB && !(k.dbg & 1)) {                           // wave-uniform
+                f32x16 hi, lo;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hi[r] = lo[r] = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < KBM; ++kb) mac6(wc[kb], xl[i][kb], hi, lo);
+                float* tp = T + 4 * kh * PG_TS + hpo[i];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float4 bb = bq[r >> 2];
+                    const float bv = (r & 3) == 0 ? bb.x : (r & 3) == 1 ? bb.y : (r & 3) == 2 ? bb.z : bb.w;
+                    tp[((r & 3) + 8 * (r >> 2)) * PG_TS] = (hi[r] + lo[r] + bv) * msk[i];
+                }
+            }
+        }
+        __syncthreads();
+        load_w(min(j + 1, k.NCH - 1));                            // in flight during phase B
+        // ---- phase B: all 16 channel pairs unrolled -- the scalar weight loads, LDS window reads and the exp / rcp chains of
+        // different channels are independent, and with two waves per SIMD that ILP is what hides their latencies
+        if (!(k.dbg & 2)) {
+            float hg[16], hv[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const int c1 = 16 * j + c, c2 = k.Hd + c1;
+                const float* w1 = dww + c1 * 9;
+                const float* w2 = dww + c2 * 9;
+                float h1 = dwb[c1] * dbmul, h2 = dwb[c2] * dbmul;
+                const float* t1 = T + c * PG_TS + wbase_lds;
+                const float* t2 = T + (16 + c) * PG_TS + wbase_lds;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        h1 = fmaf(w1[3 * dy + dx], t1[dy * PG_HW + dx], h1);
+                        h2 = fmaf(w2[3 * dy + dx], t2[dy * PG_HW + dx], h2);
+                    }
+                hg[c] = h1; hv[c] = h2;
+            }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) hg[c] = bem_gelu_fast(hg[c]) * hv[c];
+            if (ost && !(k.dbg & 4)) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) gb[(int64_t)(16 * j + c) * L] = hg[c];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" int bem_pi_gate_x6_f32(const float* x, const float* ln_w, const float* ln_b, float ln_eps, const float* Wp_gate,
+                                  const float* bias_gate, const float* dww, const float* dwb, float* g, int B, int C, int Hd,
+                                  int H, int W, void* stream) {
+    BEM_REQUIRE(x && ln_w && ln_b && Wp_gate && dww && g, "pi_gate_x6: null tensor");
+    BEM_REQUIRE(B >= 0 && B <= 65535 && C > 0 && C <= 48 && Hd > 0 && Hd % 16 == 0 && H > 0 && W > 0,
+                "pi_gate_x6: needs C <= 48 and Hd %% 16 == 0 (got C = %d, Hd = %d)", C, Hd);
+    BEM_REQUIRE(((uintptr_t)Wp_gate & 15) == 0 && (!bias_gate || ((uintptr_t)bias_gate & 15) == 0) && ((uintptr_t)dww & 15) == 0,
+                "pi_gate_x6: packed weights, bias and depthwise weights must be 16-byte aligned");
+    BEM_REQUIRE((int64_t)2 * Hd * H * W < (1ll << 31), "pi_gate_x6: plane set too large for 32-bit offsets");
+    if (B == 0) return BEM_OK;
+    PgX k;
+    k.x = x; k.ln_w = ln_w; k.ln_b = ln_b; k.ln_eps = ln_eps; k.Wp = reinterpret_cast<const u32x4*>(Wp_gate);
+    // absent biases: read the (always present, >= 2 Hd floats) depthwise weights instead and multiply by zero -- no branch next to a load
+    const float* bpi = bias_gate ? bias_gate : dww;
+    const float* dwbp = dwb ? dwb : dww;
+    const float bmul = bias_gate ? 1.f : 0.f, dbmul = dwb ? 1.f : 0.f;
+    k.C = C; k.Hd = Hd; k.H = H; k.W = W; k.KB = cdiv(C, 16); k.NCH = Hd / 16; k.tx = cdiv(W, PG_TW);
+    k.dbg = getenv("BEM_PIG_DBG") ? atoi(getenv("BEM_PIG_DBG")) : 0;
+    dim3 grid(k.tx * cdiv(H, PG_TH), 1, B);
+    hipStream_t s = (hipStream_t)stream;
+    if (k.KB <= 1) pi_gate_x6_kernel<1><<<grid, 256, 0, s>>>(k, dww, dwbp, bpi, bmul, dbmul, g);
+    else if (k.KB == 2) pi_gate_x6_kernel<2><<<grid, 256, 0, s>>>(k, dww, dwbp, bpi, bmul, dbmul, g);
+    else pi_gate_x6_kernel<3><<<grid, 256, 0, s>>>(k, dww, dwbp, bpi, bmul, dbmul, g);
+    return bem_check_launch("pi_gate_x6");
+}

@@ -605,6 +605,35 @@ def test_gate_proj_vs_unfused_chain(ops, cfg):
     close(y, torch.cat(ref), 1e-4, 2e-5, f"gate_proj vs torch {cfg}")
 
 
+@pytest.mark.parametrize("cfg", [(2, 40, 160, 16, 64, True), (4, 40, 160, 128, 128, True), (2, 24, 32, 13, 45, True), (1, 7, 16, 8, 32, False),
+                                 (3, 48, 96, 5, 3, True), (1, 16, 64, 33, 70, True)])
+def test_pi_gate_vs_unfused_chain(ops, cfg):
+    """bem_pi_gate_x6_f32 (LayerNorm + project_in + depthwise 3x3 + GELU gate, the 2Hd-channel tensor only in LDS) against the
+    two-kernel chain pw_gemm(LN) -> dwconv3x3(mode 2) and against torch in float64: image borders inside and across tiles,
+    planes that are not a multiple of the 8 x 32 tile, C not a multiple of 16, no biases, the bench's level-0 shape."""
+    B, C, Hd, H, W, bias = cfg
+    g = torch.Generator().manual_seed(C * Hd + H)
+    x = torch.randn(B, C, H, W, generator=g) * 2 + 0.3
+    lw, lb = 1 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    wi = torch.randn(2 * Hd, C, generator=g) * C ** -0.5
+    bi = 0.3 * torch.randn(2 * Hd, generator=g) if bias else None
+    wd = torch.randn(2 * Hd, 1, 3, 3, generator=g) / 3
+    bd = 0.2 * torch.randn(2 * Hd, generator=g) if bias else None
+    perm = ops.gate_order(Hd, "cpu")
+    Wg = ops.pack_pw_weight(dev(wi[perm].contiguous()), x6=True)
+    y = ops.pi_gate(dev(x), dev(lw), dev(lb), 1e-6, Wg, None if bi is None else dev(bi[perm].contiguous()), dev(wd), None if bd is None else dev(bd), Hd)
+    t = ops.pw_gemm(dev(x), ops.pack_pw_weight(dev(wi), x6=True), 2 * Hd, ln=(dev(lw), dev(lb)), ln_eps=1e-6, bias=None if bi is None else dev(bi))
+    chain = ops.dwconv3x3(t, dev(wd), None if bd is None else dev(bd), 2)
+    close(y, chain, 1e-4, 2e-5, f"pi_gate vs chain {cfg}")
+    xd = x.double()
+    mu, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
+    n = (xd - mu) / (var + 1e-6).sqrt() * lw.double()[None, :, None, None] + lb.double()[None, :, None, None]
+    tt = F.conv2d(n, wi.double()[:, :, None, None], None if bi is None else bi.double())
+    hh = F.conv2d(tt, wd.double(), None if bd is None else bd.double(), padding=1, groups=2 * Hd)
+    ref = (F.gelu(hh[:, :Hd]) * hh[:, Hd:]).float()
+    close(y, ref, 1e-4, 2e-5, f"pi_gate vs torch f64 {cfg}")
+
+
 @pytest.mark.parametrize("shape", [(2, 40, 128, 128, 3), (1, 80, 64, 64, 5), (2, 160, 32, 32, 10), (1, 6, 16, 64, 10), (1, 5, 256, 16, 5)])
 def test_ss2d_scan_row_major_form(ops, shape):
     """bem_ss2d_scan_rm (orientation 1 staged through LDS, y1 row-major) against the transposed-tensor form: identical
