@@ -1,5 +1,9 @@
-"""Model wrapper base (basicsr/models/base_model.py): device placement, checkpoint loading (:283-343), schedulers (:124-168),
-learning-rate update with linear warm-up (:209-230), loss-dict reduction (:396-421)."""
+"""Model wrapper base (basicsr/models/base_model.py): device placement, checkpoint saving / loading (:236-343), training-state
+save / resume (:345-394), schedulers (:124-168), learning-rate update with linear warm-up (:209-230), loss-dict reduction (:396-421).
+File formats are the reference's: ``<label>_<iter>.pth`` = {param_key: state_dict on CPU}, ``<iter>.state`` = {epoch, iter,
+optimizers: [state_dict], schedulers: [state_dict], best_metric, ...}; both load with ``torch.load(weights_only=True)``."""
+import os
+import time
 from collections import OrderedDict
 
 import torch
@@ -44,6 +48,58 @@ class BaseModel:
         sd = ck[param_key] if param_key is not None and param_key in ck else ck
         sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
         net.load_state_dict(sd, strict=strict)
+
+    def save(self, epoch, current_iter):
+        """Save networks and training state (overridden by the model classes)."""
+
+    def save_network(self, net, net_label, current_iter, param_key="params"):
+        """``<models>/<net_label>_<iter>.pth`` (iter -1 -> 'latest'); net / param_key may be lists of equal length (base_model.py:236-280)."""
+        it = "latest" if current_iter == -1 else current_iter
+        save_path = os.path.join(self.opt["path"]["models"], f"{net_label}_{it}.pth")
+        nets = net if isinstance(net, list) else [net]
+        keys = param_key if isinstance(param_key, list) else [param_key]
+        assert len(nets) == len(keys), "The lengths of net and param_key should be the same."
+        save_dict = {}
+        for n, k in zip(nets, keys):
+            sd = OrderedDict()
+            for name, t in self.get_bare_model(n).state_dict().items():
+                sd[name[7:] if name.startswith("module.") else name] = t.detach().cpu()
+            save_dict[k] = sd
+        os.makedirs(os.path.dirname(save_path), exist_ok=True)
+        retry, err = 3, None
+        while retry > 0:                                       # "avoid occasional writing errors" (:265-278)
+            try:
+                torch.save(save_dict, save_path)
+                return save_path
+            except OSError as e:
+                err = e
+                time.sleep(1)
+            retry -= 1
+        raise IOError(f"Cannot save {save_path}.") from err
+
+    def save_training_state(self, epoch, current_iter, **kwargs):
+        """``<training_states>/<iter>.state`` with every optimizer's and scheduler's state_dict (base_model.py:345-376); rank 0 only."""
+        if self.opt.get("rank", 0) != 0 or current_iter == -1:
+            return None
+        state = {"epoch": epoch, "iter": current_iter, "optimizers": [], "schedulers": []}
+        state.update(kwargs)
+        state["optimizers"] = [o.state_dict() for o in self.optimizers]
+        state["schedulers"] = [s.state_dict() for s in self.schedulers]
+        state["best_metric"] = kwargs["best_metric"]           # the reference requires it (:370)
+        save_path = os.path.join(self.opt["path"]["training_states"], f"{current_iter}.state")
+        os.makedirs(os.path.dirname(save_path), exist_ok=True)
+        torch.save(state, save_path)
+        return save_path
+
+    def resume_training(self, resume_state):
+        """Reload optimizers and schedulers (base_model.py:379-394)."""
+        ro, rs = resume_state["optimizers"], resume_state["schedulers"]
+        assert len(ro) == len(self.optimizers), "Wrong lengths of optimizers"
+        assert len(rs) == len(self.schedulers), "Wrong lengths of schedulers"
+        for o, sd in zip(self.optimizers, ro):
+            o.load_state_dict(sd)
+        for s, sd in zip(self.schedulers, rs):
+            s.load_state_dict(sd)
 
     # -- training-side helpers -------------------------------------------------------------------------------------
     def setup_schedulers(self):

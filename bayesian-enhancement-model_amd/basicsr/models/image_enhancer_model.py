@@ -100,3 +100,22 @@ class ImageEnhancer(BaseModel):
         self.optimizer_g.step()
         self.log_dict = self.reduce_loss_dict(loss_dict)
         return total_norm
+
+    # -- checkpoints (image_enhancer_model.py:340-370) --------------------------------------------------------------------
+    def save(self, epoch, current_iter, **kwargs):
+        self.save_network(self.net_g, "net_g", current_iter)
+        self.save_training_state(epoch, current_iter, **kwargs)
+
+    def save_best(self, best_metric, param_key="params"):
+        """``<experiments_root>/best_psnr_<psnr>_<iter>.pth``, replacing any earlier best_* file."""
+        import glob
+        import os
+        root = self.opt["path"]["experiments_root"]
+        path = os.path.join(root, f"best_psnr_{best_metric['psnr']:.2f}_{best_metric['iter']}.pth")
+        if not os.path.exists(path):
+            for f in glob.glob(f"{root}/best_*"):
+                os.remove(f)
+            sd = {(k[7:] if k.startswith("module.") else k): v.detach().cpu() for k, v in self.get_bare_model(self.net_g).state_dict().items()}
+            os.makedirs(root, exist_ok=True)
+            torch.save({param_key: sd}, path)
+        return path

@@ -1,6 +1,8 @@
 import logging
 import os
 
+from .misc import check_resume, load_resume_state  # noqa: F401
+
 
 def get_root_logger(logger_name="basicsr", log_level=logging.INFO, log_file=None):
     return logging.getLogger(logger_name)

@@ -95,3 +95,38 @@ class BemAdamW(torch.optim.Optimizer):
                 self.state[p]["step"] += 1
         self._max_norm = 0.0
         ops.bump_weight_epoch()        # parameters changed behind torch's version counters: derived-weight caches are stale
+
+    # -- checkpoints ------------------------------------------------------------------------------------------------
+    def state_dict(self):
+        """torch.optim.Optimizer layout ({'state': {idx: {step, exp_avg, exp_avg_sq}}, 'param_groups': [...]}) with standalone copies
+        of the moments (the live ones are views of the flat buffers): loads into torch.optim.AdamW and into load_state_dict below."""
+        sd = super().state_dict()
+        sd["state"] = {k: {n: (t.detach().clone() if torch.is_tensor(t) else t) for n, t in st.items()} for k, st in sd["state"].items()}
+        return sd
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        """Hyper-parameters via torch's loader, then the moments are copied INTO the flat buffers and the per-parameter state is pointed
+        back at their views (torch's loader replaces the state tensors, which would detach them from the fused step)."""
+        super().load_state_dict(state_dict)
+        steps = set()
+        for f in self._flat:
+            if f is None:
+                continue
+            off = 0
+            for p in f["params"]:
+                n = p.numel()
+                st = self.state.get(p, {})
+                m, v = f["m"][off:off + n].view(p.shape), f["v"][off:off + n].view(p.shape)
+                if "exp_avg" in st:
+                    m.copy_(st["exp_avg"]); v.copy_(st["exp_avg_sq"])
+                    steps.add(int(float(st["step"])))
+                else:
+                    m.zero_(); v.zero_()
+                    steps.add(0)
+                self.state[p] = {"step": torch.tensor(float(max(steps))), "exp_avg": m, "exp_avg_sq": v}
+                off += _align4(n)
+        if len(steps) > 1:
+            raise ValueError(f"BemAdamW.load_state_dict: parameters at different step counts {sorted(steps)} (the fused step keeps one counter)")
+        self._steps = steps.pop() if steps else 0
+        ops.bump_weight_epoch()

@@ -184,3 +184,43 @@ def test_training_option_file_and_scheduler():
         start, per, w, lo = (0, 4, 1, 0.1) if i == 0 else (4, 6, 0.5, 0.01)
         return lo + w * 0.5 * (1.0 - lo) * (1 + math.cos(math.pi * (t - start) / per))
     assert all(abs(a - ref(t)) < 1e-12 for t, a in enumerate(lrs)), (lrs, [ref(t) for t in range(10)])
+
+
+def test_checkpoint_files_and_resume_paths(tmp_path):
+    """save_network / save_training_state write the reference's file formats (base_model.py:236-280,345-376), check_resume points the
+    pretrain paths at the resumed iteration (misc.py:94-124) and --auto_resume picks the newest state (train.py:74-94)."""
+    import torch
+    from basicsr.models.base_model import BaseModel
+    from basicsr.utils import check_resume, load_resume_state
+    opt = {"name": "run", "num_gpu": 0, "is_train": True, "network_g": {"type": "x"},
+           "path": {"models": str(tmp_path / "experiments/run/models"), "training_states": str(tmp_path / "experiments/run/training_states"),
+                    "pretrain_network_g": "old.pth", "param_key_g": "params_ema", "resume_state": None}}
+    m = BaseModel(opt)
+    net = torch.nn.DataParallel(torch.nn.Linear(3, 2)) if False else torch.nn.Linear(3, 2)
+    path = m.save_network(net, "net_g", 5)
+    ck = torch.load(path, weights_only=True)
+    assert path.endswith("net_g_5.pth") and set(ck) == {"params"} and set(ck["params"]) == {"weight", "bias"}
+    assert m.save_network([net, net], "net_g", -1, param_key=["params", "params_ema"]).endswith("net_g_latest.pth")
+    opt2 = torch.optim.AdamW(net.parameters(), lr=1e-3)
+    net(torch.ones(1, 3)).sum().backward(); opt2.step()
+    m.optimizers, m.schedulers = [opt2], [torch.optim.lr_scheduler.StepLR(opt2, 10)]
+    for it in (5, 20, 100):
+        sp = m.save_training_state(3, it, best_metric={"psnr": 21.5, "iter": it})
+    st = torch.load(sp, weights_only=True)
+    assert set(st) == {"epoch", "iter", "optimizers", "schedulers", "best_metric"} and st["iter"] == 100 and st["epoch"] == 3
+    assert m.save_training_state(3, -1, best_metric={}) is None
+    with pytest.raises(KeyError):
+        m.save_training_state(3, 7)
+    # auto resume: newest state, pretrain path and param key rewritten
+    opt["auto_resume"] = True
+    state = load_resume_state(opt, experiments_root=str(tmp_path / "experiments"))
+    assert state["iter"] == 100 and opt["path"]["resume_state"].endswith("100.state")
+    assert opt["path"]["pretrain_network_g"].endswith("models/net_g_100.pth") and opt["path"]["param_key_g"] == "params"
+    m.resume_training(state)
+    assert m.optimizers[0].state_dict()["state"][0]["step"] == 1
+    # explicit resume_state path, and nothing to resume
+    opt["auto_resume"] = False
+    opt["path"]["resume_state"] = str(tmp_path / "experiments/run/training_states/20.state")
+    assert load_resume_state(opt)["iter"] == 20
+    opt["path"]["resume_state"] = None
+    assert load_resume_state(opt) is None

@@ -389,3 +389,62 @@ def test_image_enhancer_train_step_matches_oracle(dev):
         bad += int(((u_dev - u_ref).abs() > 0.05 * u_ref.abs() + 2e-6).sum())
         tot += v.numel()
     assert bad <= 0.01 * tot, f"{bad} of {tot} parameter updates differ from the oracle's"
+
+
+def test_checkpoint_resume_continues_the_run(dev, tmp_path):
+    """save (net_g_<iter>.pth + <iter>.state) after two steps, build a fresh ImageEnhancer through the resume path (load_resume_state
+    -> check_resume -> pretrain path, resume_training) and take two more steps: same learning rates and, to the noise of the
+    atomically reduced gradients, the same parameters as the run that never stopped (base_model.py:236-394, train.py:74-94,132-137).
+    The saved optimizer state also loads into torch.optim.AdamW."""
+    import copy
+    from basicsr.models import build_model
+    from basicsr.utils import load_resume_state
+    g = load_golden("g6_ddw")
+    root = tmp_path / "experiments" / "resume_run"
+    opt = dict(name="resume_run", model_type="ImageEnhancer", is_train=True, num_gpu=1, dist=False, rank=0,
+               condition=dict(type="mean", scale_down=16, noise_level=0.0),
+               network_g=dict(type="DecompDualBranchDDWavelet", in_channels=6, out_channels=3, n_feat=16, d_state=[1, 1, 1], ssm_ratio=1, mlp_ratio=4,
+                              mlp_type="gdmlp", use_pixelshuffle=True, drop_path=0.0, sam=False, stage=1, num_blocks=[2, 1, 1], decomp_model="model4"),
+               path=dict(pretrain_network_g=None, strict_load_g=True, resume_state=None, models=str(root / "models"),
+                         training_states=str(root / "training_states"), experiments_root=str(root)),
+               train=dict(total_iter=10, warmup_iter=-1, max_grad_norm=1, use_amp=False,
+                          scheduler=dict(type="CosineAnnealingRestartCyclicLR", periods=[3, 7], restart_weights=[1, 1], eta_mins=[0.0001, 0.000001]),
+                          optim_g=dict(type="AdamW", lr=2e-4, weight_decay=1e-4, betas=[0.9, 0.999]),
+                          pixel_opt=dict(type="L1Loss", loss_weight=1, reduction="mean")))
+    lq, gt = g["x"][:, :3], g["gt"]
+    gt_down = F.interpolate(gt, scale_factor=1 / 16, mode="bilinear")
+    batch = dict(lq=lq, gt=gt, gt_down=gt_down)
+
+    def steps(model, first, n):
+        lrs = []
+        for it in range(first, first + n):
+            model.update_learning_rate(it, warmup_iter=-1)
+            model.feed_train_data(batch)
+            model.optimize_parameters(it)
+            lrs.append(model.get_current_learning_rate()[0])
+        return lrs
+
+    a = build_model(copy.deepcopy(opt))
+    a.net_g.load_state_dict(g["sd"], strict=False)
+    steps(a, 1, 2)
+    a.save(0, 2, best_metric={"psnr": 20.0, "iter": 2})
+    assert a.save_best({"psnr": 20.0, "iter": 2}).endswith("best_psnr_20.00_2.pth")
+    lr_a = steps(a, 3, 2)
+
+    opt_b = copy.deepcopy(opt)
+    opt_b["auto_resume"] = True
+    state = load_resume_state(opt_b, experiments_root=str(tmp_path / "experiments"))
+    assert state["iter"] == 2 and opt_b["path"]["pretrain_network_g"].endswith("net_g_2.pth")
+    b = build_model(opt_b)                                   # loads net_g_2.pth through pretrain_network_g
+    b.resume_training(state)
+    assert b.optimizer_g._steps == 2
+    lr_b = steps(b, state["iter"] + 1, 2)
+    assert lr_a == lr_b, (lr_a, lr_b)
+    pa, pb = dict(a.net_g.named_parameters()), dict(b.net_g.named_parameters())
+    worst = max(float((pa[k].detach() - pb[k].detach()).abs().max()) for k in pa)
+    assert worst <= 2e-5, worst                              # an un-resumed optimizer (moments at zero) differs by ~ lr = 2e-4 per step
+    # cross-load into torch's optimizer: same state layout
+    ref_opt = torch.optim.AdamW([{"params": gp["params"]} for gp in b.optimizer_g.param_groups], lr=1e-3)
+    ref_opt.load_state_dict(b.optimizer_g.state_dict())
+    st = ref_opt.state_dict()["state"]
+    assert all(float(v["step"]) == 4 for v in st.values()) and len(st) == sum(len(gp["params"]) for gp in b.optimizer_g.param_groups)
