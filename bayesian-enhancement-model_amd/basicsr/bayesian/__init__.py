@@ -14,8 +14,10 @@ def _convert_leaf(m, cfg):
         return None
     if cfg.get("pretrain"):
         new.mu_weight.data.copy_(m.weight.data.view_as(new.mu_weight))
+        new.prior_mu_weight.data.copy_(new.mu_weight.data)
         if m.bias is not None:
             new.mu_bias.data.copy_(m.bias.data)
+            new.prior_mu_bias.data.copy_(m.bias.data)
     return new.to(m.weight.device)
 
 
@@ -46,4 +48,11 @@ def set_prediction_type(model, deterministic=True):
 
 
 def get_kl_loss(m):
-    raise NotImplementedError("KL / EMA-prior training of the Bayesian layers is a later row of SURVEY.md section 8f")
+    """Sum over the Bayesian leaves below ``m`` of KL(q || EMA prior) (tools.py:76-84; base_layer.py:26-40): a 0-dim device tensor
+    whose backward accumulates into mu / rho .grad.  None when ``m`` holds no Bayesian leaf, as in the reference."""
+    from bem import autograd as ag
+    leaves = [layer for layer in m.modules() if hasattr(layer, "kl_terms")]
+    if not leaves:
+        return None
+    params = [p for layer in leaves for t in layer.kl_terms() for p in t[:2]]
+    return ag.KLFn.apply(leaves, *params)

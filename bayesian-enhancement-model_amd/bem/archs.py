@@ -498,6 +498,9 @@ class PatchMerging(nn.Module):
         self.reduction = PwConv2d(4 * dim, 2 * dim, bias=False)
 
     def forward(self, x):
+        if grad_mode(self):
+            ps = [p for p in (self.norm.weight, self.norm.bias, self.reduction.weight) if p.requires_grad]
+            return ag.LnPwFn.apply(ag.SpaceToDepthFn.apply(x), self.norm, self.reduction, *ps)
         s = ops.space_to_depth(x)
         Wp, _ = self.reduction.gemm_weights(x.shape[0])
         return ops.pw_gemm(s, Wp, 2 * self.dim, ln=(self.norm.weight.detach(), self.norm.bias.detach()), ln_eps=self.norm.eps)
@@ -527,6 +530,11 @@ class DualUpSample(nn.Module):
         self.up_b = nn.Sequential(PwConv2d(c, c, bias=True), nn.PReLU(), _Up2(), PwConv2d(c, c // 2, bias=False))
 
     def forward(self, x):
+        if grad_mode(self):
+            xa, xb = ag.fork(x)
+            p = self.up_p[3](ag.PixelShuffle2Fn.apply(ag.PReLUFn.apply(self.up_p[0](xa), self.up_p[1].weight)))
+            b = self.up_b[3](ag.BilinearUpFn.apply(ag.PReLUFn.apply(self.up_b[0](xb), self.up_b[1].weight), 2))
+            return self.conv(p, x2=b, in_mode=2)
         p = self.up_p[3](self.up_p[2](self.up_p[0](x, prelu=self.up_p[1].weight.detach())))
         b = self.up_b[3](self.up_b[2](self.up_b[0](x, prelu=self.up_b[1].weight.detach())))
         return self.conv(p, x2=b, in_mode=2)
@@ -579,7 +587,11 @@ class SubNetwork(nn.Module):
         fea, enc = x, []
         for blk, down in self.encoder_layers:
             fea = blk(fea)
-            enc.append(fea)
+            if grad_mode(self):
+                fea, skip = ag.fork(fea)
+                enc.append(skip)
+            else:
+                enc.append(fea)
             fea = down(fea)
         fea = self.bottleneck(fea)
         for i, (up, fusion, blk) in enumerate(self.decoder_layers):
@@ -611,10 +623,10 @@ class Network(nn.Module):
 
     def forward(self, x, mask=None):
         _need_cuda(x)
-        if self.training and mask is not None:
-            raise BemNativeError("Network: the masked-image-modelling training path is not part of this round")
-        from .modules import _SAMPLE_CTX, SampleCtx, sampling
+        from .modules import _SAMPLE_CTX, _TRAIN_STEP, SampleCtx, sampling
         ctx = _SAMPLE_CTX[0]
+        if grad_mode(self):
+            return self._forward_train(x, mask, ctx)
         if ctx is None:      # one weight sample per batch element, fresh Philox streams for this forward
             ctx = SampleCtx(x.shape[0], None, seed=torch.initial_seed() & 0xFFFFFFFF)
         with torch.no_grad(), sampling(ctx):
@@ -625,4 +637,31 @@ class Network(nn.Module):
             # proj(fea0 + dec) = proj_nobias(fea0) + proj(dec)   (UNet_arch.py:361,470-472; conv is linear)
             base = ops.conv2d(fea0, self.proj.weight.detach(), None, pad=1)
             out = self.proj(dec, res1=base)
+        return [x, out]
+
+    def _forward_train(self, x, mask, ctx):
+        """Training forward (UNet_arch.py:447-474 with module.training): one weight sample per Bayesian leaf for the whole batch
+        (conv.py:100-104 draws eps once per forward), EMA prior update before the draw, optional MIM token mix, autograd nodes over the
+        HIP kernels.  The returned prediction carries the anchor that folds the sampled-weight gradients into mu / rho after backward."""
+        from .modules import _TRAIN_STEP, SampleCtx, sampling
+        if ctx is None:
+            ctx = SampleCtx(1, None, seed=torch.initial_seed() & 0xFFFFFFFF)
+        if ctx.nsets != 1:
+            raise BemNativeError("Network: a training forward shares one weight sample across the batch (SampleCtx(nsets=1))")
+        step = ag.BayesStep()
+        prev = _TRAIN_STEP[0]
+        _TRAIN_STEP[0] = step
+        ops.bump_weight_epoch()              # every training forward draws new weights: packed / transposed copies of the last draw are stale
+        try:
+            with sampling(ctx):
+                set_module_paths(self)
+                fea = self.first_conv(x.contiguous())
+                if mask is not None:
+                    fea = ag.MaskTokenFn.apply(fea, mask, self.mask_token)
+                fa, fb = ag.fork(fea)
+                dec = self.subnets[0](fa)
+                out = self.proj(ag.AddFn.apply(fb, dec))
+                out = ag.BayesAnchorFn.apply(out, step)
+        finally:
+            _TRAIN_STEP[0] = prev
         return [x, out]

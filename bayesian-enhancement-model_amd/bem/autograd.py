@@ -68,6 +68,19 @@ def _w2d(w):
     return w.detach().reshape(w.shape[0], -1)
 
 
+def wb(m):
+    """(weight, bias | None) tensors of a leaf: nn.Conv2d / nn.Linear parameters, or -- for a Bayesian leaf in a training forward -- the
+    weights it sampled for this forward (modules._BayesBase.train_sample); their .grad is the buffer the reparameterisation kernel
+    later folds into mu / rho."""
+    if hasattr(m, "mu_weight"):
+        if m.deterministic:
+            return m.mu_weight, (m.mu_bias if m.bias else None)
+        if getattr(m, "_ws", None) is None:
+            raise RuntimeError("Bayesian leaf: no weight sample is active (training forwards run under Network.forward)")
+        return m._ws, m._bs
+    return m.weight, m.bias
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # small nodes
 # ------------------------------------------------------------------------------------------------------------------
@@ -293,26 +306,27 @@ class VSSBlockFn(Function):
         Ci, R, L = op.d_inner, op.dt_rank, H * W
         n1, n2, on = blk.norm, blk.norm2, op.out_norm
         pi, dwc, po = mlp.project_in, mlp.dwconv, mlp.project_out
-        Hd = po.weight.shape[1]
+        (piw, pib), (dww, dwb), (pow_, pob) = wb(pi), wb(dwc), wb(po)
+        Hd = pow_.shape[1]
         # ---- gdMlp: out = x2 + W_o g + b_o, g = GELU(h1) h2, h = dw(t2) + b, t2 = W_i LN2(x2) + b_i
-        ops.pw_wgrad_(dout, g, grad_of(po.weight), dbias=None if po.bias is None else grad_of(po.bias))
-        dg = ops.pw_gemm(dout, _pack(po, "T", [po.weight], lambda: _w2d(po.weight).t()), Hd)
-        dh = ops.dwact_bwd(t2, dwc.weight.detach(), None if dwc.bias is None else dwc.bias.detach(), dg, grad_of(dwc.weight),
-                           None if dwc.bias is None else grad_of(dwc.bias), 2)
+        ops.pw_wgrad_(dout, g, grad_of(pow_), dbias=None if pob is None else grad_of(pob))
+        dg = ops.pw_gemm(dout, _pack(po, "T", [pow_], lambda: _w2d(pow_).t()), Hd)
+        dh = ops.dwact_bwd(t2, dww.detach(), None if dwb is None else dwb.detach(), dg, grad_of(dww), None if dwb is None else grad_of(dwb), 2)
         del dg
-        dt2 = ops.dwconv3x3(dh, _derived(dwc).get("flip", [dwc.weight], lambda: dwc.weight.detach().flip(2, 3).contiguous()), None, mode=0)
+        dt2 = ops.dwconv3x3(dh, _derived(dwc).get("flip", [dww], lambda: dww.detach().flip(2, 3).contiguous()), None, mode=0)
         del dh
-        dn2 = ops.pw_gemm(dt2, _pack(pi, "T", [pi.weight], lambda: _w2d(pi.weight).t()), C)
+        dn2 = ops.pw_gemm(dt2, _pack(pi, "T", [piw], lambda: _w2d(piw).t()), C)
         dx2, nrm = ops.ln_bwd(x2, dn2, n2.weight.detach(), n2.bias.detach(), n2.eps, grad_of(n2.weight), grad_of(n2.bias), dres=dout)
         del dn2
-        ops.pw_wgrad_(dt2, nrm, grad_of(pi.weight), dbias=None if pi.bias is None else grad_of(pi.bias))
+        ops.pw_wgrad_(dt2, nrm, grad_of(piw), dbias=None if pib is None else grad_of(pib))
         del dt2, nrm
         # ---- SS2D: x2 = x + W_out LN_on(y0 + y1)
         opw = op.out_proj
-        dysn = ops.pw_gemm(dx2, _pack(opw, "T", [opw.weight], lambda: _w2d(opw.weight).t()), Ci)
+        oww, owb = wb(opw)
+        dysn = ops.pw_gemm(dx2, _pack(opw, "T", [oww], lambda: _w2d(oww).t()), Ci)
         dys, nys = ops.ln_bwd(y0, dysn, on.weight.detach(), on.bias.detach(), on.eps, grad_of(on.weight), grad_of(on.bias), x2=y1)
         del dysn
-        ops.pw_wgrad_(dx2, nys, grad_of(opw.weight), dbias=None if opw.bias is None else grad_of(opw.bias))
+        ops.pw_wgrad_(dx2, nys, grad_of(oww), dbias=None if owb is None else grad_of(owb))
         del nys
         wall, dtw, dtb, A, Ds = op._scan_params()
         dysT = ops.transpose_planes(dys)
@@ -332,15 +346,16 @@ class VSSBlockFn(Function):
         dxc = ops.add(dxc, ops.transpose_planes(dx1T.view(B, Ci, W, H)))
         del dx0, dx1T, dxd, dxd0, dxd1
         cv = op.conv2d
-        dpre = ops.dwact_bwd(t, cv.weight.detach(), None if cv.bias is None else cv.bias.detach(), dxc, grad_of(cv.weight),
-                             None if cv.bias is None else grad_of(cv.bias), 1)
-        dt = ops.dwconv3x3(dpre, _derived(cv).get("flip", [cv.weight], lambda: cv.weight.detach().flip(2, 3).contiguous()), None, mode=0)
+        cvw, cvb = wb(cv)
+        dpre = ops.dwact_bwd(t, cvw.detach(), None if cvb is None else cvb.detach(), dxc, grad_of(cvw), None if cvb is None else grad_of(cvb), 1)
+        dt = ops.dwconv3x3(dpre, _derived(cv).get("flip", [cvw], lambda: cvw.detach().flip(2, 3).contiguous()), None, mode=0)
         del dpre, dxc
         ipw = op.in_proj
-        dn = ops.pw_gemm(dt, _pack(ipw, "T", [ipw.weight], lambda: _w2d(ipw.weight).t()), C)
+        iww, iwb = wb(ipw)
+        dn = ops.pw_gemm(dt, _pack(ipw, "T", [iww], lambda: _w2d(iww).t()), C)
         need_dx = ctx.needs_input_grad[0]
         dx, nrm = ops.ln_bwd(x, dn, n1.weight.detach(), n1.bias.detach(), n1.eps, grad_of(n1.weight), grad_of(n1.bias), dres=dx2)
-        ops.pw_wgrad_(dt, nrm, grad_of(ipw.weight), dbias=None if ipw.bias is None else grad_of(ipw.bias))
+        ops.pw_wgrad_(dt, nrm, grad_of(iww), dbias=None if iwb is None else grad_of(iwb))
         return (dx if need_dx else None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 
@@ -350,3 +365,168 @@ def vssblock_params(blk):
 
 def vssblock(blk, x):
     return VSSBlockFn.apply(x, blk, *vssblock_params(blk))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Stage-I U-Net pieces (basicsr/archs/UNet_arch.py): PatchMerging, DualUpSample, MIM token mix, outer residual
+# ------------------------------------------------------------------------------------------------------------------
+class AddFn(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.add(a.contiguous(), b.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+class LnPwFn(Function):
+    """LayerNorm2d + bias-free / biased 1x1 layer (PatchMerging.reduction(norm(x)), UNet_arch.py:80)."""
+
+    @staticmethod
+    def forward(ctx, x, norm, layer, *params):
+        x = x.contiguous()
+        Wp, b = layer.gemm_weights(x.shape[0])
+        ctx.save_for_backward(x)
+        ctx.norm, ctx.layer = norm, layer
+        return ops.pw_gemm(x, Wp, layer.weight.shape[0], ln=(norm.weight.detach(), norm.bias.detach()), ln_eps=norm.eps, bias=b)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x,) = ctx.saved_tensors
+        n, m = ctx.norm, ctx.layer
+        dout = dout.contiguous()
+        w, b = wb(m)
+        dn = ops.pw_gemm(dout, _pack(m, "T", [w], lambda: _w2d(w).t()), x.shape[1])
+        dx, nrm = ops.ln_bwd(x, dn, n.weight.detach(), n.bias.detach(), n.eps, grad_of(n.weight), grad_of(n.bias))
+        ops.pw_wgrad_(dout, nrm, grad_of(w), dbias=None if b is None else grad_of(b))
+        return (dx if ctx.needs_input_grad[0] else None, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
+
+
+class SpaceToDepthFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        return ops.space_to_depth(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.depth_to_space(g.contiguous())
+
+
+class PixelShuffle2Fn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        return ops.pixel_shuffle2(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.pixel_unshuffle2(g.contiguous())
+
+
+class BilinearUpFn(Function):
+    @staticmethod
+    def forward(ctx, x, s):
+        ctx.s = s
+        return ops.bilinear_up(x.contiguous(), s)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.bilinear_up_bwd(g.contiguous(), ctx.s), None
+
+
+class PReLUFn(Function):
+    @staticmethod
+    def forward(ctx, x, slope):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        ctx.slope = slope
+        return ops.prelu(x, slope.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return ops.prelu_bwd(x, ctx.slope.detach(), g.contiguous(), grad_of(ctx.slope)), None
+
+
+class MaskTokenFn(Function):
+    """fea * (1 - w) + mask_token * w  (UNet_arch.py:463-466)."""
+
+    @staticmethod
+    def forward(ctx, fea, mask, token):
+        mask = mask.to(fea.dtype).contiguous()
+        ctx.save_for_backward(mask)
+        ctx.token = token
+        return ops.mask_token(fea.contiguous(), mask, token.detach().reshape(-1).contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return ops.mask_token_bwd(g.contiguous(), mask, grad_of(ctx.token).view(-1)), None, None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Bayesian leaves in training (basicsr/bayesian/conv.py:84-114, linear.py:61-90, tools.py:76-84)
+# ------------------------------------------------------------------------------------------------------------------
+class BayesStep:
+    """One training forward's Bayesian bookkeeping: the leaves that drew a weight sample, to be folded back into mu / rho once the
+    whole backward pass has run (the sampled weight's gradient is complete only then)."""
+
+    def __init__(self):
+        self.leaves = []
+        self.done = False
+
+    def finish(self):
+        if self.done:
+            return
+        self.done = True
+        for m in self.leaves:
+            m.fold_sample_grads()
+
+
+class BayesAnchorFn(Function):
+    """Identity on the network output; its backward (the first node of the pass) queues BayesStep.finish to run after the pass."""
+
+    @staticmethod
+    def forward(ctx, out, step):
+        ctx.step = step
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, g):
+        torch.autograd.Variable._execution_engine.queue_callback(ctx.step.finish)
+        return g, None
+
+
+class KLFn(Function):
+    """sum over the Bayesian leaves of kl_div(q || EMA prior).mean() for weight (+ bias)  (get_kl_loss, tools.py:76-84)."""
+
+    @staticmethod
+    def forward(ctx, leaves, *params):
+        out = torch.zeros(1, device=params[0].device, dtype=torch.float32)
+        for m in leaves:
+            for mu, rho, pmu, prho in m.kl_terms():
+                ops.bnn_kl_(mu.detach(), rho.detach(), pmu, prho, out)
+        ctx.leaves = leaves
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.reshape(1).contiguous().float()
+        for m in ctx.leaves:
+            for mu, rho, pmu, prho in m.kl_terms():
+                ops.bnn_kl_bwd_(mu.detach(), rho.detach(), pmu, prho, g, grad_of(mu), grad_of(rho))
+        return (None,) * (1 + len(ctx.needs_input_grad) - 1)
+
+
+class ScaledSumFn(Function):
+    """a + c * b for two device scalars (l_total = l_pix + 0.01 / mini_batch * l_kl, condition_generator_model.py:185-190)."""
+
+    @staticmethod
+    def forward(ctx, a, b, c):
+        ctx.c = c
+        return ops.add(a.reshape(1).contiguous(), b.reshape(1).contiguous(), c).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        g1 = g.reshape(1).contiguous()
+        return g, ops.add(torch.zeros_like(g1), g1, ctx.c).reshape(()), None

@@ -87,6 +87,7 @@ class SampleCtx:
 
 
 _SAMPLE_CTX: List[Optional[SampleCtx]] = [None]
+_TRAIN_STEP: List[Optional["ag.BayesStep"]] = [None]      # set by Network.forward for the span of one training forward
 
 
 class sampling:
@@ -231,6 +232,54 @@ class _BayesBase(nn.Module):
     def _rho_init(self):
         return math.log(math.expm1(abs(self.sigma_init)) + 1e-20)
 
+    def _register_priors(self):
+        """prior_* buffers (non-persistent, as conv.py:57-70): copies of the freshly initialised mu / rho; the training forward moves
+        them towards the current parameters (threshold EMA).  Loading a checkpoint does not touch them -- the reference's behaviour."""
+        for kind in ("weight", "bias") if self.bias else ("weight",):
+            self.register_buffer(f"prior_mu_{kind}", getattr(self, f"mu_{kind}").detach().clone(), persistent=False)
+            self.register_buffer(f"prior_rho_{kind}", getattr(self, f"rho_{kind}").detach().clone(), persistent=False)
+        self._ws = self._bs = self._eps_w = self._eps_b = self._sample_owner = None
+
+    def _train_sample(self):
+        """Once per training forward (conv.py:84-104): move the prior, draw eps, form w = mu + softplus(rho) eps.  The sampled tensors
+        are what the forward / backward kernels see as this leaf's weight and bias (bem.autograd.wb)."""
+        step = _TRAIN_STEP[0]
+        if step is None:
+            raise BemNativeError("Bayesian leaves: a training-mode forward runs under Network.forward, which scopes the weight sample")
+        if self._sample_owner is step:
+            return
+        ctx = _SAMPLE_CTX[0]
+        d = min(self.decay, (1 + self.step) / (10 + self.step))
+        for kind in ("weight", "bias") if self.bias else ("weight",):
+            mu, rho = getattr(self, f"mu_{kind}"), getattr(self, f"rho_{kind}")
+            ops.bnn_prior_ema_(getattr(self, f"prior_mu_{kind}"), getattr(self, f"prior_rho_{kind}"), mu.detach(), rho.detach(), d)
+            if ctx.eps is not None:
+                e = ctx.eps[f"{self.module_path}.{kind}"].reshape((1,) + tuple(mu.shape)).contiguous()
+            else:
+                e = ops.randn((1,) + tuple(mu.shape), mu.device, ctx.seed, ctx.next_stream())
+            w = ops.bnn_sample(mu.detach(), rho.detach(), 1, e)[0]
+            if kind == "weight":
+                self._ws, self._eps_w = w, e
+            else:
+                self._bs, self._eps_b = w, e
+        self.step += 1
+        self._sample_owner = step
+        step.leaves.append(self)
+
+    def fold_sample_grads(self):
+        """dmu += dw, drho += dw eps sigmoid(rho) for the sampled weight and bias of the finished backward pass, then drop the sample."""
+        for w, e, kind in ((self._ws, self._eps_w, "weight"), (self._bs, self._eps_b, "bias")):
+            if w is not None and w.grad is not None:
+                mu, rho = getattr(self, f"mu_{kind}"), getattr(self, f"rho_{kind}")
+                ops.bnn_reparam_bwd_(w.grad, e, rho.detach(), ag.grad_of(mu), ag.grad_of(rho))
+        self._ws = self._bs = self._eps_w = self._eps_b = self._sample_owner = None
+
+    def kl_terms(self):
+        out = [(self.mu_weight, self.rho_weight, self.prior_mu_weight, self.prior_rho_weight)]
+        if self.bias:
+            out.append((self.mu_bias, self.rho_bias, self.prior_mu_bias, self.prior_rho_bias))
+        return out
+
     def _sampled(self, B, packed_mk=None):
         """(weights (nsets,*shape), bias (nsets,C)|None, nsets) for this forward; with ``packed_mk = (M, K)`` the sampled
         weights come back already packed for the x6 GEMM (stochastic mode only)."""
@@ -238,7 +287,8 @@ class _BayesBase(nn.Module):
         if self.deterministic:
             return self.mu_weight.detach()[None], (self.mu_bias.detach()[None] if self.bias else None), 1
         if self.training:
-            raise BemNativeError("Bayesian layers: training-mode forward (EMA prior + KL) is not part of this round")
+            self._train_sample()             # raises outside Network's training forward (e.g. train() mode under no_grad: call eval())
+            return self._ws[None], (self._bs[None] if self.bias else None), 1
         if ctx is None:      # leaf used outside a Network forward: one-off context (fresh epoch)
             ctx = SampleCtx(B, None, seed=torch.initial_seed() & 0xFFFFFFFF)
         ns = ctx.nsets
@@ -280,6 +330,7 @@ class Conv2dReparameterization(_BayesBase):
         if bias:
             self.mu_bias.data.zero_()
             self.rho_bias.data.fill_(self._rho_init())
+        self._register_priors()
         self._is_dw = groups == in_channels and groups == out_channels and tuple(ks) == (3, 3)
         self._is_pw = groups == 1 and tuple(ks) == (1, 1)
         if not (self._is_dw or self._is_pw):
@@ -287,7 +338,7 @@ class Conv2dReparameterization(_BayesBase):
 
     # pointwise interface
     def gemm_weights(self, B):
-        if self.deterministic or not ops.USE_X6:
+        if self.deterministic or not ops.USE_X6 or self.training:
             w, b, ns = self._sampled(B)
             return ops.pack_pw_weight(w.reshape(ns, self.out_channels, self.in_channels).contiguous()), b
         Wp, b, _ = self._sampled(B, (self.out_channels, self.in_channels))
@@ -314,9 +365,10 @@ class Linear2dReparameterization(_BayesBase):
         if bias:
             self.mu_bias.data.zero_()
             self.rho_bias.data.fill_(self._rho_init())
+        self._register_priors()
 
     def gemm_weights(self, B):
-        if self.deterministic or not ops.USE_X6:
+        if self.deterministic or not ops.USE_X6 or self.training:
             w, b, ns = self._sampled(B)
             return ops.pack_pw_weight(w.contiguous()), b
         Wp, b, _ = self._sampled(B, (self.out_features, self.in_features))

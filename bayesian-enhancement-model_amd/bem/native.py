@@ -76,6 +76,16 @@ SIGNATURES = {
     "bem_pw_x6_packed_elems": [I, I],
     "bem_bnn_sample_pack_x6": [P, P, P, P, I, I, I, U64, U64, I, P],
     "bem_gate_proj_x6_f32": [P, P, I64, P, I64, P, I64, P, I64, P, P, I, I, I, I, I, P],
+    "bem_bnn_prior_ema_f32": [P, P, P, P, F, I64, P],
+    "bem_bnn_kl_f32": [P, P, P, P, I64, P, P],
+    "bem_bnn_kl_bwd_f32": [P, P, P, P, I64, P, P, P, P],
+    "bem_bnn_reparam_bwd_f32": [P, P, P, P, P, I64, P],
+    "bem_mask_token_f32": [P, P, P, P, I, I, I, I, P],
+    "bem_mask_token_bwd_f32": [P, P, P, P, I, I, I, I, P],
+    "bem_depth_to_space_f32": [P, P, I, I, I, I, P],
+    "bem_prelu_f32": [P, P, P, I64, P],
+    "bem_prelu_bwd_f32": [P, P, P, P, P, I64, P],
+    "bem_bilinear_up_bwd_f32": [P, P, I, I, I, I, I, P],
     "bem_pi_gate_x6_f32": [P, P, P, F, P, P, P, P, P, I, I, I, I, I, P],
     "bem_conv3x3_x6_f32": [P, I64, P, P, P, P, P, I, I, I, I, I, I, P],
     "bem_conv4x4s2_x6_f32": [P, I64, P, P, P, P, P, I, I, I, I, I, I, P],

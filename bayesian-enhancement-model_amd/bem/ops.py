@@ -658,6 +658,98 @@ def pixel_shuffle2(x):
     return out
 
 
+# ------------------------------------------------------------------- Stage-I training pieces ----
+def bnn_prior_ema_(prior_mu, prior_rho, mu, rho, decay):
+    for t, nm in ((prior_mu, "prior_mu"), (prior_rho, "prior_rho"), (mu, "mu"), (rho, "rho")):
+        _chk(t, nm)
+    if not (prior_mu.shape == prior_rho.shape == mu.shape == rho.shape):
+        raise ValueError("bnn_prior_ema_: shapes differ")
+    check(lib().bem_bnn_prior_ema_f32(_p(prior_mu), _p(prior_rho), _p(mu), _p(rho), float(decay), mu.numel(), _stream()), "bnn_prior_ema")
+
+
+def bnn_kl_(mu, rho, prior_mu, prior_rho, out):
+    """out[0] += kl_div(mu, softplus(rho), prior_mu, softplus(prior_rho)).mean()"""
+    for t, nm in ((prior_mu, "prior_mu"), (prior_rho, "prior_rho"), (mu, "mu"), (rho, "rho"), (out, "out")):
+        _chk(t, nm)
+    if not (prior_mu.shape == prior_rho.shape == mu.shape == rho.shape) or out.numel() != 1:
+        raise ValueError("bnn_kl_: shapes")
+    check(lib().bem_bnn_kl_f32(_p(mu), _p(rho), _p(prior_mu), _p(prior_rho), mu.numel(), _p(out), _stream()), "bnn_kl")
+
+
+def bnn_kl_bwd_(mu, rho, prior_mu, prior_rho, g, dmu, drho):
+    for t, nm in ((prior_mu, "prior_mu"), (prior_rho, "prior_rho"), (mu, "mu"), (rho, "rho"), (g, "g"), (dmu, "dmu"), (drho, "drho")):
+        _chk(t, nm)
+    if not (prior_mu.shape == prior_rho.shape == mu.shape == rho.shape == dmu.shape == drho.shape) or g.numel() != 1:
+        raise ValueError("bnn_kl_bwd_: shapes")
+    check(lib().bem_bnn_kl_bwd_f32(_p(mu), _p(rho), _p(prior_mu), _p(prior_rho), mu.numel(), _p(g), _p(dmu), _p(drho), _stream()), "bnn_kl_bwd")
+
+
+def bnn_reparam_bwd_(gw, eps, rho, dmu, drho):
+    for t, nm in ((gw, "gw"), (eps, "eps"), (rho, "rho"), (dmu, "dmu"), (drho, "drho")):
+        _chk(t, nm)
+    if not (gw.numel() == eps.numel() == rho.numel() == dmu.numel() == drho.numel()):
+        raise ValueError("bnn_reparam_bwd_: sizes differ")
+    check(lib().bem_bnn_reparam_bwd_f32(_p(gw), _p(eps), _p(rho), _p(dmu), _p(drho), rho.numel(), _stream()), "bnn_reparam_bwd")
+
+
+def mask_token(fea, mask, token):
+    _chk(fea, "fea"); _chk(mask, "mask"); _chk(token, "token")
+    B, C, H, W = fea.shape
+    if tuple(mask.shape) != (B, H, W) or token.numel() != C:
+        raise ValueError(f"mask_token: mask {tuple(mask.shape)} / token {tuple(token.shape)} vs features {tuple(fea.shape)}")
+    out = torch.empty_like(fea)
+    check(lib().bem_mask_token_f32(_p(fea), _p(mask), _p(token), _p(out), B, C, H, W, _stream()), "mask_token")
+    return out
+
+
+def mask_token_bwd(dout, mask, dtoken):
+    _chk(dout, "dout"); _chk(mask, "mask"); _chk(dtoken, "dtoken")
+    B, C, H, W = dout.shape
+    if tuple(mask.shape) != (B, H, W) or dtoken.numel() != C:
+        raise ValueError("mask_token_bwd: shapes")
+    dfea = torch.empty_like(dout)
+    check(lib().bem_mask_token_bwd_f32(_p(dout), _p(mask), _p(dfea), _p(dtoken), B, C, H, W, _stream()), "mask_token_bwd")
+    return dfea
+
+
+def depth_to_space(d4):
+    _chk(d4, "d4")
+    B, C4, h, w = d4.shape
+    if C4 % 4:
+        raise ValueError("depth_to_space: channels % 4")
+    dx = torch.empty(B, C4 // 4, 2 * h, 2 * w, device=d4.device, dtype=d4.dtype)
+    check(lib().bem_depth_to_space_f32(_p(d4), _p(dx), B, C4 // 4, 2 * h, 2 * w, _stream()), "depth_to_space")
+    return dx
+
+
+def prelu(x, slope):
+    _chk(x, "x"); _chk(slope, "slope")
+    if slope.numel() != 1:
+        raise ValueError("prelu: one shared slope (nn.PReLU())")
+    out = torch.empty_like(x)
+    check(lib().bem_prelu_f32(_p(x), _p(slope), _p(out), x.numel(), _stream()), "prelu")
+    return out
+
+
+def prelu_bwd(x, slope, dout, dslope):
+    _chk(x, "x"); _chk(slope, "slope"); _chk(dout, "dout"); _chk(dslope, "dslope")
+    if slope.numel() != 1 or dslope.numel() != 1 or dout.shape != x.shape:
+        raise ValueError("prelu_bwd: shapes")
+    dx = torch.empty_like(x)
+    check(lib().bem_prelu_bwd_f32(_p(x), _p(slope), _p(dout), _p(dx), _p(dslope), x.numel(), _stream()), "prelu_bwd")
+    return dx
+
+
+def bilinear_up_bwd(dout, s):
+    _chk(dout, "dout")
+    B, C, Ho, Wo = dout.shape
+    if Ho % s or Wo % s:
+        raise ValueError("bilinear_up_bwd: output size not a multiple of the scale")
+    dx = torch.empty(B, C, Ho // s, Wo // s, device=dout.device, dtype=dout.dtype)
+    check(lib().bem_bilinear_up_bwd_f32(_p(dout), _p(dx), B, C, Ho // s, Wo // s, int(s), _stream()), "bilinear_up_bwd")
+    return dx
+
+
 # --------------------------------------------------------------------------- Bayesian / MC ----
 def bnn_sample(mu, rho, nsets, eps=None, seed=0, stream_id=0):
     """w[s] = mu + log1p(exp(rho)) * eps[s];  eps None -> Philox N(0,1) keyed by (seed, stream_id)."""

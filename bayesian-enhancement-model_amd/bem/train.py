@@ -82,9 +82,12 @@ class BemAdamW(torch.optim.Optimizer):
         return self._norm
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, skip=()):
+        """``skip``: parameters that took no part in this iteration's graph.  torch.optim.AdamW leaves a parameter whose ``.grad`` is None
+        untouched (no decay, no moment update); the fused kernel runs over the whole flat buffer, so their slices are put back after it."""
         if closure is not None:
             raise NotImplementedError("BemAdamW.step: closures are not supported")
+        keep = [(p, p.detach().clone(), self.state[p]["exp_avg"].clone(), self.state[p]["exp_avg_sq"].clone()) for p in skip]
         self._steps += 1
         for group, f in zip(self.param_groups, self._flat):
             if f is None:
@@ -93,6 +96,9 @@ class BemAdamW(torch.optim.Optimizer):
                             max_norm=self._max_norm, sumsq=self._sumsq if self._max_norm > 0 else None, norm_out=self._norm)
             for p in f["params"]:
                 self.state[p]["step"] += 1
+        for p, val, m, v in keep:
+            p.copy_(val); self.state[p]["exp_avg"].copy_(m); self.state[p]["exp_avg_sq"].copy_(v)
+            self.state[p]["step"] -= 1
         self._max_norm = 0.0
         ops.bump_weight_epoch()        # parameters changed behind torch's version counters: derived-weight caches are stale
 

@@ -387,6 +387,42 @@ int bem_grad_sumsq_f32(const float* g, int64_t n, double* acc, void* stream);
 int bem_adamw_step_f32(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                        float weight_decay, int step, float max_norm, const double* sumsq, float* norm_out, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Stage-I training: ConditionGenerator.optimize_parameters,
+ * basicsr/models/condition_generator_model.py:176-218.  Everything else of that step runs on the Stage-II training entry points.
+ * --------------------------------------------------------------------------------------------- */
+
+/* Threshold-EMA prior of a Bayesian leaf (basicsr/bayesian/conv.py:86-98, linear.py:63-74):
+ * prior = decay * prior + (1 - decay) * current, for mu and rho; the caller passes decay = min(layer.decay, (1 + step) / (10 + step)). */
+int bem_bnn_prior_ema_f32(float* prior_mu, float* prior_rho, const float* mu, const float* rho, float decay, int64_t n, void* stream);
+
+/* out[0] += mean( log sp - log sq + (sq^2 + (mu - prior_mu)^2) / (2 sp^2) - 0.5 ), s = log1p(exp(rho))  (base_layer.py:26-40 kl_div). */
+int bem_bnn_kl_f32(const float* mu, const float* rho, const float* prior_mu, const float* prior_rho, int64_t n, float* out, void* stream);
+
+/* gradient of g[0] * (that mean) accumulated into dmu / drho (g: one float on the device, the upstream gradient of the KL term). */
+int bem_bnn_kl_bwd_f32(const float* mu, const float* rho, const float* prior_mu, const float* prior_rho, int64_t n, const float* g,
+                       float* dmu, float* drho, void* stream);
+
+/* Reparameterisation w = mu + log1p(exp(rho)) * eps (conv.py:100-104): dmu += gw, drho += gw * eps * sigmoid(rho). */
+int bem_bnn_reparam_bwd_f32(const float* gw, const float* eps, const float* rho, float* dmu, float* drho, int64_t n, void* stream);
+
+/* Masked-image-modelling mix (basicsr/archs/UNet_arch.py:463-466): out = fea * (1 - w) + token[c] * w, w = mask (B,H,W);
+ * backward: dfea = dout * (1 - w), dtoken[c] += sum dout * w. */
+int bem_mask_token_f32(const float* fea, const float* mask, const float* token, float* out, int B, int C, int H, int W, void* stream);
+int bem_mask_token_bwd_f32(const float* dout, const float* mask, float* dfea, float* dtoken, int B, int C, int H, int W, void* stream);
+
+/* Inverse of bem_space_to_depth_f32 (= backward of PatchMerging's gather, UNet_arch.py:74-78): d4 (B,4C,H/2,W/2) -> dx (B,C,H,W). */
+int bem_depth_to_space_f32(const float* d4, float* dx, int B, int C, int H, int W, void* stream);
+
+/* nn.PReLU() with one shared slope (DualUpSample, UNet_arch.py:106,120): forward, and backward dx = dout * (x >= 0 ? 1 : a),
+ * dslope[0] += sum dout * x over x < 0. */
+int bem_prelu_f32(const float* x, const float* slope, float* out, int64_t n, void* stream);
+int bem_prelu_bwd_f32(const float* x, const float* slope, const float* dout, float* dx, float* dslope, int64_t n, void* stream);
+
+/* Adjoint of bem_bilinear_up_f32 (nn.Upsample(scale_factor = s, bilinear, align_corners = False), UNet_arch.py:121-123):
+ * dout (B,C,H*s,W*s) -> dx (B,C,H,W), zeroed by the call. */
+int bem_bilinear_up_bwd_f32(const float* dout, float* dx, int B, int C, int H, int W, int s, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -463,11 +463,14 @@ def dual_upsample_ref(sd: SD, pre: str, x):
     return F.conv2d(torch.cat([p, b], 1), sd[pre + "conv.weight"])
 
 
-def network_ref(sd: SD, x, src: Optional[EpsSource] = None, scan=selective_scan_ref, pre: str = ""):
-    """Network.forward in eval mode (mask path inactive), one SubNetwork (stage=1), use_pixelshuffle=True.
-    src=None -> deterministic (mu) prediction; otherwise weights are sampled layer by layer in
-    execution order, weight then bias (conv.py:106-110)."""
+def network_ref(sd: SD, x, src: Optional[EpsSource] = None, scan=selective_scan_ref, pre: str = "", mask=None):
+    """Network.forward, one SubNetwork (stage=1), use_pixelshuffle=True.  src=None -> deterministic (mu) prediction; otherwise
+    weights are sampled layer by layer in execution order, weight then bias (conv.py:106-110).  ``mask`` (B,H,W) is the
+    masked-image-modelling mix of training mode (UNet_arch.py:463-466); eval mode never passes one."""
     fea0 = F.conv2d(x, sd[pre + "first_conv.weight"], sd[pre + "first_conv.bias"], padding=1)
+    if mask is not None:
+        w = mask.unsqueeze(1).type_as(fea0)
+        fea0 = fea0 * (1.0 - w) + sd[pre + "mask_token"].expand(fea0.shape[0], -1, fea0.shape[2], fea0.shape[3]) * w
     s = pre + "subnets.0."
     nl = 0
     while f"{s}encoder_layers.{nl}.0.blocks.0.norm.weight" in sd:
@@ -595,6 +598,64 @@ def train_step_ref(sd: SD, lq, gt, conds, *, stage2=ddwavelet_ref, scale=16, lr=
         losses.append(float(loss))
         norms.append(float(gn))
     return dict(loss=losses, grad_norm=norms, grads=grads0, params={k: v.detach() for k, v in params.items()}, out=out.detach())
+
+
+# ----------------------------------------------------------------------------------------------
+# (f)2  Stage-I training step     basicsr/models/condition_generator_model.py:176-218,
+#       basicsr/bayesian/conv.py:78-114, linear.py:55-90, base_layer.py:26-40, tools.py:76-84
+# ----------------------------------------------------------------------------------------------
+
+def kl_div_ref(mu_q, sigma_q, mu_p, sigma_p):
+    return (torch.log(sigma_p) - torch.log(sigma_q) + (sigma_q ** 2 + (mu_q - mu_p) ** 2) / (2 * (sigma_p ** 2)) - 0.5).mean()
+
+
+def bnn_layers_ref(sd: SD):
+    """prefixes ('...in_proj.') of the Bayesian leaves in module order (= state-dict order)."""
+    return [k[:-len("mu_weight")] for k in sd if k.endswith("mu_weight")]
+
+
+def stage1_train_step_ref(sd: SD, prior: SD, lq, gt, eps_steps, masks, *, mini_batch=8, kl_weight=0.01, decay=0.998, lr=2e-4,
+                          betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4, max_grad_norm=1.0, bnn_step0=0, scan=selective_scan_ref):
+    """``ConditionGenerator.optimize_parameters`` for ``len(eps_steps)`` iterations.  ``sd``: the BNN-converted Network's state dict
+    (every entry is a parameter); ``prior``: {'<layer>.prior_mu_weight' ...} buffers; ``eps_steps[i]``: the N(0,1) draws of iteration i
+    ('<layer>.weight' / '.bias'); ``masks[i]``: MIM mask or None.  Per training forward every Bayesian leaf first moves its prior
+    (threshold EMA with d = min(decay, (1 + t) / (10 + t)), t = forwards so far), then samples w = mu + softplus(rho) eps; the loss is
+    kl_weight * sum_layers KL(q || prior) / mini_batch + L1.  A parameter that took no part in the graph keeps ``grad = None`` and is
+    skipped by AdamW (mask_token in an iteration without a mask)."""
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+    prior = {k: v.detach().clone() for k, v in prior.items()}
+    layers = bnn_layers_ref(sd)
+    opt = torch.optim.AdamW(list(params.values()), lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+    kls, pixs, norms, grads0, out = [], [], [], None, None
+    for it, (e, m) in enumerate(zip(eps_steps, masks)):
+        opt.zero_grad()
+        t = bnn_step0 + it
+        d = min(decay, (1 + t) / (10 + t))
+        with torch.no_grad():
+            for L in layers:
+                for kind in ("weight", "bias"):
+                    if L + "mu_" + kind in params:
+                        for mr in ("mu", "rho"):
+                            prior[f"{L}prior_{mr}_{kind}"] = d * prior[f"{L}prior_{mr}_{kind}"] + (1 - d) * params[f"{L}{mr}_{kind}"].detach()
+        out = network_ref(params, lq, EpsSource(e), scan, mask=m)
+        kl = None
+        for L in layers:
+            for kind in ("weight", "bias"):
+                if L + "mu_" + kind in params:
+                    term = kl_div_ref(params[f"{L}mu_{kind}"], torch.log1p(torch.exp(params[f"{L}rho_{kind}"])),
+                                      prior[f"{L}prior_mu_{kind}"], torch.log1p(torch.exp(prior[f"{L}prior_rho_{kind}"])))
+                    kl = term if kl is None else kl + term
+        pix = (out - gt).abs().mean()
+        (kl_weight * kl / mini_batch + pix).backward()
+        if it == 0:
+            grads0 = {k: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)) for k, p in params.items()}
+        live = [p for p in params.values() if p.grad is not None]
+        norms.append(float(torch.nn.utils.clip_grad_norm_(live, max_grad_norm)) if max_grad_norm else
+                     float(torch.sqrt(sum((p.grad ** 2).sum() for p in live))))
+        opt.step()
+        kls.append(float(kl.detach())); pixs.append(float(pix.detach()))
+    return dict(l_kl=kls, l_pix=pixs, grad_norm=norms, grads=grads0, params={k: v.detach() for k, v in params.items()}, prior=prior,
+                out=out.detach())
 
 
 # ----------------------------------------------------------------------------------------------

@@ -171,6 +171,10 @@ def test_training_option_file_and_scheduler():
     tr = opt["train"]
     assert tr["optim_g"] == {"type": "AdamW", "lr": 2e-4, "weight_decay": 1e-4, "betas": [0.9, 0.999]} and tr["max_grad_norm"] == 1
     assert tr["pixel_opt"]["type"] == "L1Loss" and "perceptual_opt" not in tr and opt["path"]["experiments_root"].endswith("DecompDualBranch2DDWavelet_4")
+    # Stage-I: the keys ConditionGenerator.optimize_parameters reads (condition_generator_model.py:176-218)
+    cg = parse(os.path.join(ROOT, "bayesian-enhancement-model_amd", "Options", "CG_UNet_LOLv1.yml"), is_train=True)
+    assert cg["model_type"] == "ConditionGenerator" and cg["datasets"]["train"]["mini_batch_sizes"][0] == 8
+    assert cg["train"]["scheduler"]["periods"][0] == 150000 and cg["train"]["mixing_augs"]["mixup"] is False and cg["train"]["pixel_opt"]["type"] == "L1Loss"
     p = torch.nn.Parameter(torch.zeros(1))
     o = torch.optim.SGD([p], lr=1.0)
     s = CosineAnnealingRestartCyclicLR(o, periods=[4, 6], restart_weights=[1, 0.5], eta_mins=[0.1, 0.01])

@@ -136,3 +136,30 @@ def test_g10_training_step():
         close(r["grads"][k], v, 1e-5, 1e-9)
     for k, v in g["params"].items():
         close(r["params"][k], v, 0, 1e-6)      # two AdamW steps of 2e-4; Adam amplifies rounding-level gradient differences near g = 0
+
+
+def test_g11_stage1_train_step():
+    """oracle.stage1_train_step_ref against two iterations of the reference's Stage-I training step (its own Network + BNN leaves in
+    train() mode, get_kl_loss, AdamW): KL and pixel loss, gradient norm, every gradient of iteration 1, parameters and EMA priors after
+    iteration 2 (iteration 1 with a MIM mask, iteration 2 without: mask_token then has no gradient and AdamW skips it)."""
+    g = load_golden("g11_stage1_train")
+    r = O.stage1_train_step_ref(g["sd"], g["prior0"], g["lq"], g["gt"], [g["eps0"], g["eps1"]], [g["mask"], None],
+                                mini_batch=int(g["mini_batch"]))
+    for i in range(2):
+        assert abs(r["l_kl"][i] - float(g["l_kl"][i])) <= 2e-6 * max(1.0, abs(float(g["l_kl"][i]))), (i, r["l_kl"], g["l_kl"])
+        assert abs(r["l_pix"][i] - float(g["l_pix"][i])) <= 2e-6, (i, r["l_pix"], g["l_pix"])
+        assert abs(r["grad_norm"][i] - float(g["grad_norm"][i])) <= 1e-4 * float(g["grad_norm"][i]), (i, r["grad_norm"], g["grad_norm"])
+    for k, v in g["grads"].items():
+        assert torch.allclose(r["grads"][k], v, rtol=1e-3, atol=1e-5 * float(v.abs().max()) + 1e-9), k
+    # Adam's first updates are sign-like (lr * g / (|g| + eps)): an element whose gradient sits at rounding level may move the other
+    # way.  Every parameter within two full updates, and all but 0.5 % of the elements within 1e-6.
+    bad = tot = 0
+    for k, v in g["params"].items():
+        d = (r["params"][k] - v).abs()
+        assert float(d.max()) <= 2 * 2 * 2e-4 * 1.05, k
+        bad += int((d > 1e-6).sum()); tot += v.numel()
+    assert bad <= 0.005 * tot, (bad, tot)
+    for k, v in g["prior2"].items():
+        pre, name = k.rsplit(".", 1)
+        assert torch.allclose(r["prior"][pre + "." + name], v, rtol=0, atol=2e-4), k       # carries (1 - d) of the updated parameters
+        assert float(((r["prior"][pre + "." + name] - v).abs() > 1e-6).float().mean()) <= 0.01, k

@@ -448,3 +448,144 @@ def test_checkpoint_resume_continues_the_run(dev, tmp_path):
     ref_opt.load_state_dict(b.optimizer_g.state_dict())
     st = ref_opt.state_dict()["state"]
     assert all(float(v["step"]) == 4 for v in st.values()) and len(st) == sum(len(gp["params"]) for gp in b.optimizer_g.param_groups)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Stage-I training
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["prelu", "bilinear", "depth_to_space", "mask_token", "kl", "reparam"])
+def test_stage1_training_kernels(dev, case):
+    """The small Stage-I training kernels against torch autograd of the reference formulas (UNet_arch.py:74-78,97-127,463-466;
+    base_layer.py:26-40; conv.py:100-104)."""
+    from bem import ops
+    g = G(5)
+    d = lambda t: t.to(dev)
+    if case == "prelu":
+        x = torch.randn(2, 5, 7, 9, generator=g, requires_grad=True); a = torch.tensor([0.25], requires_grad=True)
+        dy = torch.randn(2, 5, 7, 9, generator=g)
+        y = F.prelu(x, a); y.backward(dy)
+        assert torch.equal(ops.prelu(d(x.detach()), d(a.detach())).cpu(), y.detach())
+        da = torch.zeros(1, device=dev)
+        dx = ops.prelu_bwd(d(x.detach()), d(a.detach()), d(dy), da)
+        close(dx, x.grad, 1e-6, 1e-7, "prelu dx"); close(da, a.grad, 1e-5, 1e-6, "prelu dslope")
+    elif case == "bilinear":
+        for s_ in (2, 16):
+            x = torch.randn(2, 3, 4, 5, generator=g, requires_grad=True)
+            dy = torch.randn(2, 3, 4 * s_, 5 * s_, generator=g)
+            F.interpolate(x, scale_factor=s_, mode="bilinear", align_corners=False).backward(dy)
+            close(ops.bilinear_up_bwd(d(dy), s_), x.grad, 1e-5, 1e-5, f"bilinear x{s_} adjoint")
+    elif case == "depth_to_space":
+        x = torch.randn(2, 3, 6, 8, generator=g)
+        assert torch.equal(ops.depth_to_space(ops.space_to_depth(d(x))).cpu(), x)
+    elif case == "mask_token":
+        fea = torch.randn(2, 6, 4, 5, generator=g, requires_grad=True); tok = torch.randn(1, 6, 1, 1, generator=g, requires_grad=True)
+        m = (torch.rand(2, 4, 5, generator=g) < 0.5).float(); dy = torch.randn(2, 6, 4, 5, generator=g)
+        w = m.unsqueeze(1)
+        y = fea * (1.0 - w) + tok.expand(2, -1, 4, 5) * w; y.backward(dy)
+        close(ops.mask_token(d(fea.detach()), d(m), d(tok.detach().reshape(-1))), y.detach(), 1e-6, 1e-7, "mask_token")
+        dt = torch.zeros(6, device=dev)
+        close(ops.mask_token_bwd(d(dy), d(m), dt), fea.grad, 1e-6, 1e-7, "mask_token dfea")
+        close(dt, tok.grad.reshape(-1), 1e-5, 1e-6, "mask_token dtoken")
+    elif case == "kl":
+        from oracle import bem_oracle as O
+        mu = torch.randn(700, generator=g, requires_grad=True); rho = (torch.randn(700, generator=g) - 3).requires_grad_(True)
+        pmu, prho = mu.detach() + 0.1 * torch.randn(700, generator=g), rho.detach() + 0.2 * torch.randn(700, generator=g)
+        kl = O.kl_div_ref(mu, torch.log1p(torch.exp(rho)), pmu, torch.log1p(torch.exp(prho)))
+        (0.37 * kl).backward()
+        out = torch.zeros(1, device=dev)
+        ops.bnn_kl_(d(mu.detach()), d(rho.detach()), d(pmu), d(prho), out)
+        close(out, kl.detach().reshape(1), 2e-5, 1e-6, "kl value")
+        dmu, drho = torch.zeros(700, device=dev), torch.zeros(700, device=dev)
+        ops.bnn_kl_bwd_(d(mu.detach()), d(rho.detach()), d(pmu), d(prho), torch.tensor([0.37], device=dev), dmu, drho)
+        close(dmu, mu.grad, 1e-4, 1e-7, "kl dmu"); close(drho, rho.grad, 1e-4, 1e-7, "kl drho")
+        pm, pr = d(pmu).clone(), d(prho).clone()
+        ops.bnn_prior_ema_(pm, pr, d(mu.detach()), d(rho.detach()), 0.1)
+        close(pm, 0.1 * pmu + 0.9 * mu.detach(), 1e-6, 1e-7, "prior ema mu"); close(pr, 0.1 * prho + 0.9 * rho.detach(), 1e-6, 1e-7, "prior ema rho")
+    else:
+        mu = torch.randn(300, generator=g, requires_grad=True); rho = (torch.randn(300, generator=g) - 3).requires_grad_(True)
+        e, gw = torch.randn(300, generator=g), torch.randn(300, generator=g)
+        (mu + torch.log1p(torch.exp(rho)) * e).backward(gw)
+        dmu, drho = torch.zeros(300, device=dev), torch.zeros(300, device=dev)
+        ops.bnn_reparam_bwd_(d(gw), d(e), d(rho.detach()), dmu, drho)
+        close(dmu, mu.grad, 1e-6, 1e-7, "reparam dmu"); close(drho, rho.grad, 1e-5, 1e-7, "reparam drho")
+
+
+def _cg_opt(n_feat=16, num_blocks=(2, 1, 1), mini_batch=8, periods=(1, 9)):
+    return dict(name="cg", model_type="ConditionGenerator", is_train=True, num_gpu=1, dist=False, rank=0, sigma_init=0.05, selective=True,
+                condition=dict(type="mean", scale_down=16, noise_level=0.1),
+                datasets=dict(train=dict(mini_batch_sizes=[mini_batch])),
+                network_g=dict(type="Network", in_channels=3, out_channels=3, n_feat=n_feat, d_state=[1, 1, 1], ssm_ratio=1, mlp_ratio=4,
+                               mlp_type="gdmlp", use_pixelshuffle=True, drop_path=0.0, sam=False, stage=1, num_blocks=list(num_blocks)),
+                path=dict(pretrain_network_g=None, strict_load_g=True, resume_state=None),
+                train=dict(total_iter=10, warmup_iter=-1, max_grad_norm=1, use_amp=False, mixing_augs=dict(mixup=False),
+                           scheduler=dict(type="CosineAnnealingRestartCyclicLR", periods=list(periods), restart_weights=[1, 1], eta_mins=[0.0002, 0.000001]),
+                           optim_g=dict(type="AdamW", lr=2e-4, weight_decay=1e-4, betas=[0.9, 0.999]),
+                           pixel_opt=dict(type="L1Loss", loss_weight=1, reduction="mean")))
+
+
+def test_condition_generator_train_step_golden(dev):
+    """ConditionGenerator.optimize_parameters (registry seam) for two iterations against the REFERENCE's own Stage-I training step
+    (tests/golden/g11_stage1_train.npz: its Network + Bayesian leaves in train() mode, get_kl_loss, AdamW) with the recorded eps injected:
+    KL and pixel losses, gradient norm, every gradient of iteration 1 (mu, rho, LayerNorm, PReLU, mask token, ...), parameters and
+    EMA priors after iteration 2.  Iteration 1 uses the MIM mask, iteration 2 runs past the first scheduler period (mask dropped,
+    mask_token skipped by the optimizer)."""
+    from basicsr.models import build_model
+    from bem.modules import SampleCtx, sampling
+    g = load_golden("g11_stage1_train")
+    model = build_model(_cg_opt(mini_batch=int(g["mini_batch"])))
+    net = model.net_g
+    missing, unexpected = net.load_state_dict(g["sd"], strict=True)
+    for k, v in g["prior0"].items():                       # the reference's priors sit at ITS random initial values: install them
+        mod, name = k.rsplit(".", 1)
+        getattr(net.get_submodule(mod), name).copy_(v.to(dev))
+    for it in range(2):
+        model.feed_train_data(dict(lq_down=g["lq"], gt=g["gt"], gt_down=g["gt"], mask=g["mask"]))
+        with sampling(SampleCtx(1, {k: v.to(dev) for k, v in g[f"eps{it}"].items()})):
+            tn = model.optimize_parameters(it + 1)
+        assert abs(float(model.log_dict["l_kl"]) - float(g["l_kl"][it])) <= 1e-4 * max(1.0, abs(float(g["l_kl"][it]))), (it, float(model.log_dict["l_kl"]), g["l_kl"])
+        assert abs(float(model.log_dict["l_pix"]) - float(g["l_pix"][it])) <= 1e-5, (it, float(model.log_dict["l_pix"]), g["l_pix"])
+        assert abs(float(tn) - float(g["grad_norm"][it])) <= 1e-3 * float(g["grad_norm"][it]), (it, float(tn), g["grad_norm"])
+    named = dict(net.named_parameters())
+    bad = tot = 0
+    for k, v in g["params"].items():
+        dlt = (named[k].detach().cpu() - v).abs()
+        assert float(dlt.max()) <= 2 * 2 * 2e-4 * 1.05, k
+        bad += int((dlt > 2e-6).sum()); tot += v.numel()
+    assert bad <= 0.01 * tot, (bad, tot)
+    for k, v in g["prior2"].items():
+        mod, name = k.rsplit(".", 1)
+        got = getattr(net.get_submodule(mod), name).cpu()
+        assert torch.allclose(got, v, rtol=0, atol=2e-4) and float(((got - v).abs() > 2e-6).float().mean()) <= 0.02, k
+
+
+def test_stage1_training_gradients_golden(dev):
+    """Every parameter gradient of one Stage-I training iteration (loss = 0.01 * KL / mini_batch + L1, MIM mask on) against the
+    reference's (g11 'grads'): read from .grad after backward, before any optimizer step."""
+    from basicsr.bayesian import convert2bnn_selective, get_kl_loss
+    from basicsr.archs import build_network
+    from bem import autograd as ag
+    from bem.modules import SampleCtx, sampling
+    g = load_golden("g11_stage1_train")
+    opt = _cg_opt()
+    net = build_network(opt["network_g"])
+    convert2bnn_selective(net, {"sigma_init": 0.05, "decay": 0.998, "pretrain": False})
+    net = net.to(dev)
+    net.load_state_dict(g["sd"], strict=True)
+    for k, v in g["prior0"].items():
+        mod, name = k.rsplit(".", 1)
+        getattr(net.get_submodule(mod), name).copy_(v.to(dev))
+    net.train()
+    with sampling(SampleCtx(1, {k: v.to(dev) for k, v in g["eps0"].items()})):
+        _, pred = net(g["lq"].to(dev), mask=g["mask"].to(dev))
+    kl = get_kl_loss(net)
+    pix = ag.l1_loss(pred, g["gt"].to(dev))
+    ag.ScaledSumFn.apply(pix, kl, 0.01 / int(g["mini_batch"])).backward()
+    assert abs(float(kl.detach()) - float(g["l_kl"][0])) <= 1e-4 * max(1.0, float(g["l_kl"][0]))
+    for k, p in net.named_parameters():
+        ref = g["grads"][k]
+        assert p.grad is not None, k
+        scale = float(ref.abs().max())
+        err = float((p.grad.cpu() - ref).abs().max())
+        assert err <= 2e-3 * scale + 1e-7, (k, err, scale)
+    # a second backward through the same graph is refused by autograd; a second FORWARD draws a new sample and a new EMA step
+    assert all(m._ws is None for m in net.modules() if hasattr(m, "kl_terms"))
