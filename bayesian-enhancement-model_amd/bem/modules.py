@@ -430,9 +430,9 @@ class gdMlp(nn.Module):
             def prep():
                 perm = ops.gate_order(Hd, pi.weight.device)
                 return (ops.pack_pw_weight(pi.weight.detach().reshape(2 * Hd, C)[perm].contiguous(), x6=True),
-                        None if pi.bias is None else pi.bias.detach()[perm].contiguous())
-            Wg, bg = self._cache.get("pi_gate", [t for t in (pi.weight, pi.bias) if t is not None], prep)
-            w, bw = dw.dw_weights(B)
+                        None if pi.bias is None else pi.bias.detach()[perm].contiguous()) + \
+                    ops.dw_gate_params(dw.weight.detach(), None if dw.bias is None else dw.bias.detach(), Hd)
+            Wg, bg, w, bw = self._cache.get("pi_gate", [t for t in (pi.weight, pi.bias, dw.weight, dw.bias) if t is not None], prep)
             g = ops.pi_gate(x, norm.weight.detach(), norm.bias.detach(), norm.eps, Wg, bg, w, bw, Hd)
             Wp, b = self.project_out.gemm_weights(B)
             return ops.pw_gemm(g, Wp, _out_features(self.project_out), bias=b, res=x)

@@ -319,14 +319,22 @@ def pi_gate_supported(C, Hd):
     return USE_X6 and C <= 48 and Hd % 16 == 0
 
 
+def dw_gate_params(dww, dwb, Hd):
+    """depthwise (2Hd,1,3,3) / (2Hd) parameters -> the (Hd,9,2) / (Hd,2) per-gate-channel interleave of bem_pi_gate_x6_f32."""
+    w = dww.reshape(2, Hd, 9).permute(1, 2, 0).contiguous()
+    return w, (None if dwb is None else dwb.reshape(2, Hd).t().contiguous())
+
+
 def pi_gate(x, ln_w, ln_b, ln_eps, Wp_gate, bias_gate, dww, dwb, Hd):
     """GELU(h1) * h2 with [h1; h2] = dw3x3(project_in(LayerNorm2d(x))) in one kernel (bem_pi_gate_x6_f32).
-    Wp_gate = pack_pw_weight(W_i[gate_order(Hd)], x6=True), bias_gate = b_i[gate_order(Hd)]; dww (2Hd,1,3,3), dwb (2Hd) | None."""
+    Wp_gate = pack_pw_weight(W_i[gate_order(Hd)], x6=True), bias_gate = b_i[gate_order(Hd)]; dww, dwb = dw_gate_params(...)."""
     _chk(x, "x"); _chk(ln_w, "ln_w"); _chk(ln_b, "ln_b"); _chk(Wp_gate, "Wp_gate"); _chk(bias_gate, "bias_gate", optional=True)
     _chk(dww, "dww"); _chk(dwb, "dwb", optional=True)
     B, C, H, W = x.shape
     if not pi_gate_supported(C, Hd):
         raise ValueError(f"pi_gate: C = {C} (<= 48) / Hd = {Hd} (% 16) not supported")
+    if tuple(dww.shape) != (Hd, 9, 2) or (dwb is not None and tuple(dwb.shape) != (Hd, 2)):
+        raise ValueError("pi_gate: depthwise parameters must come from dw_gate_params")
     if ln_w.numel() != C or ln_b.numel() != C or dww.numel() != 2 * Hd * 9 or (dwb is not None and dwb.numel() != 2 * Hd) \
             or (bias_gate is not None and bias_gate.numel() != 2 * Hd):
         raise ValueError("pi_gate: parameter shapes")

@@ -12,14 +12,15 @@
 //     Hd + 16j ..], so that one 32-row MFMA tile yields both gate inputs of 16 output channels.
 //   * per chunk j:  phase A  t(32 rows x 340 halo pixels) = W_j * x on the bf16 matrix cores (exact 3-limb products, see
 //     pw_gemm_x6.hip) + bias, forced to zero outside the image (the depthwise conv zero-pads t, not x), into LDS;
-//     phase B  wave w takes output rows 2w, 2w+1 (lanes 0-31 / 32-63), lane = column: 3x3 window from LDS, depthwise
-//     weights are wave-uniform (scalar loads), erf-form GELU gate, one 128-byte store per half-wave and channel.
-//     Measured (64 x 40 x 128 x 128, Hd 160): 650 us against 358 + 363 us for project_in + depthwise gate as two kernels, with
-//     2.7 GB less HBM traffic.  The phases do not overlap in practice: with either phase disabled the time drops by that
-//     phase's full share (prologue 115 us, phase A 207 us, phase B 424 us; scripts/pig_time.py), and delaying every second
-//     workgroup by one phase changes nothing.  (A packed-math variant -- float2 (h1, h2) LDS layout, two pixels per lane, v_pk_fma -- has 40 % fewer VALU and LDS
-//     instructions and was slower, 730 vs 650 us: the kernel is bound by latency at two waves per SIMD, not by issue.)
-//   * two workgroups share a CU (45 KB LDS each), so one's MFMA phase overlaps the other's VALU/LDS phase.
+//     phase B  wave w takes output rows 2w, 2w+1 (lanes 0-31 / 32-63), lane = column: 3x3 window of (h1, h2) float2 pairs from
+//     LDS, both gate inputs advance in one packed FMA against the host-interleaved (w1, w2) depthwise pairs (wave-uniform:
+//     scalar loads), erf-form GELU gate, one 128-byte store per half-wave and channel.
+//     Measured (64 x 40 x 128 x 128, Hd 160, inside the eval bench): 560 us against 358 + 363 us for project_in + depthwise gate as two
+//     kernels, with 2.7 GB less HBM traffic.  The phases do not overlap in practice: with either phase disabled the time drops
+//     by that phase's full share (scripts/pig_time.py).  Steps so far: vector loads of the uniform depthwise weights -> scalar
+//     loads (820 -> 660 us); all 16 channels of a chunk unrolled (650); (h1, h2) as float2 in LDS + packed FMAs (560).  A form with
+//     two pixels per lane and an 8-iteration channel loop had fewer instructions still and was slower (730 us): the kernel is
+//     bound by latency at two waves per SIMD, the next lever is occupancy (the resident x limbs are 108 VGPRs).
 #include "bem_common.h"
 #include "x6_common.h"
 #include <stdlib.h>
@@ -40,7 +41,7 @@ constexpr int PG_BPW = (PG_NPB + 3) / 4, PG_TS = PG_NPB * 32;
 template <int KBM>
 __global__ __launch_bounds__(256, 2) void pi_gate_x6_kernel(PgX k, const float* __restrict__ dww, const float* __restrict__ dwb,
                                                             const float* __restrict__ bpi, float bmul, float dbmul, float* __restrict__ g) {
-    __shared__ float T[32 * PG_TS];
+    __shared__ f32x2 T[16 * PG_TS];                       // [gate channel c][halo pixel] = (h1 input, h2 input)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kh = lane >> 5, n = lane & 31;
     const int b = blockIdx.z;
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
@@ -148,13 +149,18 @@ __global__ __launch_bounds__(256, 2) void pi_gate_x6_kernel(PgX k, const float* 
                 for (int r = 0; r < 16; ++r) hi[r] = lo[r] = 0.f;
 #pragma unroll
                 for (int kb = 0; kb < KBM; ++kb) mac6(wc[kb], xl[i][kb], hi, lo);
-                float* tp = T + 4 * kh * PG_TS + hpo[i];
+                f32x2* tp = T + 4 * kh * PG_TS + hpo[i];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float4 bb = bq[r >> 2];
-                    const float bv = (r & 3) == 0 ? bb.x : (r & 3) == 1 ? bb.y : (r & 3) == 2 ? bb.z : bb.w;
-                    tp[((r & 3) + 8 * (r >> 2)) * PG_TS] = (hi[r] + lo[r] + bv) * msk[i];
-                }
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        // accumulator rows 8q + e + 4kh (h1 input of gate channel c = 8q + e + 4kh) and 16 + the same (its h2 input)
+                        const int r = 4 * q + e;
+                        const float4 b1 = bq[q], b2 = bq[q + 2];
+                        const float v1 = e == 0 ? b1.x : e == 1 ? b1.y : e == 2 ? b1.z : b1.w;
+                        const float v2 = e == 0 ? b2.x : e == 1 ? b2.y : e == 2 ? b2.z : b2.w;
+                        tp[(8 * q + e) * PG_TS] = f32x2{(hi[r] + lo[r] + v1) * msk[i], (hi[r + 8] + lo[r + 8] + v2) * msk[i]};
+                    }
             }
         }
         __syncthreads();
@@ -165,20 +171,15 @@ __global__ __launch_bounds__(256, 2) void pi_gate_x6_kernel(PgX k, const float* 
             float hg[16], hv[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
-                const int c1 = 16 * j + c, c2 = k.Hd + c1;
-                const float* w1 = dww + c1 * 9;
-                const float* w2 = dww + c2 * 9;
-                float h1 = dwb[c1] * dbmul, h2 = dwb[c2] * dbmul;
-                const float* t1 = T + c * PG_TS + wbase_lds;
-                const float* t2 = T + (16 + c) * PG_TS + wbase_lds;
+                const int cg = 16 * j + c;
+                const f32x2* wq = reinterpret_cast<const f32x2*>(dww) + cg * 9;      // host-interleaved (w1, w2) per tap
+                f32x2 acc = reinterpret_cast<const f32x2*>(dwb)[cg] * dbmul;
+                const f32x2* tp = T + c * PG_TS + wbase_lds;
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) {
-                        h1 = fmaf(w1[3 * dy + dx], t1[dy * PG_HW + dx], h1);
-                        h2 = fmaf(w2[3 * dy + dx], t2[dy * PG_HW + dx], h2);
-                    }
-                hg[c] = h1; hv[c] = h2;
+                    for (int dx = 0; dx < 3; ++dx) acc = __builtin_elementwise_fma(wq[3 * dy + dx], tp[dy * PG_HW + dx], acc);
+                hg[c] = acc[0]; hv[c] = acc[1];
             }
 #pragma unroll
             for (int c = 0; c < 16; ++c) hg[c] = bem_gelu_fast(hg[c]) * hv[c];
@@ -194,27 +195,27 @@ __global__ __launch_bounds__(256, 2) void pi_gate_x6_kernel(PgX k, const float* 
 }  // namespace
 
 extern "C" int bem_pi_gate_x6_f32(const float* x, const float* ln_w, const float* ln_b, float ln_eps, const float* Wp_gate,
-                                  const float* bias_gate, const float* dww, const float* dwb, float* g, int B, int C, int Hd,
+                                  const float* bias_gate, const float* dw_gate, const float* dwb_gate, float* g, int B, int C, int Hd,
                                   int H, int W, void* stream) {
-    BEM_REQUIRE(x && ln_w && ln_b && Wp_gate && dww && g, "pi_gate_x6: null tensor");
+    BEM_REQUIRE(x && ln_w && ln_b && Wp_gate && dw_gate && g, "pi_gate_x6: null tensor");
     BEM_REQUIRE(B >= 0 && B <= 65535 && C > 0 && C <= 48 && Hd > 0 && Hd % 16 == 0 && H > 0 && W > 0,
                 "pi_gate_x6: needs C <= 48 and Hd %% 16 == 0 (got C = %d, Hd = %d)", C, Hd);
-    BEM_REQUIRE(((uintptr_t)Wp_gate & 15) == 0 && (!bias_gate || ((uintptr_t)bias_gate & 15) == 0) && ((uintptr_t)dww & 15) == 0,
+    BEM_REQUIRE(((uintptr_t)Wp_gate & 15) == 0 && (!bias_gate || ((uintptr_t)bias_gate & 15) == 0) && ((uintptr_t)dw_gate & 15) == 0,
                 "pi_gate_x6: packed weights, bias and depthwise weights must be 16-byte aligned");
     BEM_REQUIRE((int64_t)2 * Hd * H * W < (1ll << 31), "pi_gate_x6: plane set too large for 32-bit offsets");
     if (B == 0) return BEM_OK;
     PgX k;
     k.x = x; k.ln_w = ln_w; k.ln_b = ln_b; k.ln_eps = ln_eps; k.Wp = reinterpret_cast<const u32x4*>(Wp_gate);
     // absent biases: read the (always present, >= 2 Hd floats) depthwise weights instead and multiply by zero -- no branch next to a load
-    const float* bpi = bias_gate ? bias_gate : dww;
-    const float* dwbp = dwb ? dwb : dww;
-    const float bmul = bias_gate ? 1.f : 0.f, dbmul = dwb ? 1.f : 0.f;
+    const float* bpi = bias_gate ? bias_gate : dw_gate;
+    const float* dwbp = dwb_gate ? dwb_gate : dw_gate;
+    const float bmul = bias_gate ? 1.f : 0.f, dbmul = dwb_gate ? 1.f : 0.f;
     k.C = C; k.Hd = Hd; k.H = H; k.W = W; k.KB = cdiv(C, 16); k.NCH = Hd / 16; k.tx = cdiv(W, PG_TW);
     k.dbg = getenv("BEM_PIG_DBG") ? atoi(getenv("BEM_PIG_DBG")) : 0;
     dim3 grid(k.tx * cdiv(H, PG_TH), 1, B);
     hipStream_t s = (hipStream_t)stream;
-    if (k.KB <= 1) pi_gate_x6_kernel<1><<<grid, 256, 0, s>>>(k, dww, dwbp, bpi, bmul, dbmul, g);
-    else if (k.KB == 2) pi_gate_x6_kernel<2><<<grid, 256, 0, s>>>(k, dww, dwbp, bpi, bmul, dbmul, g);
-    else pi_gate_x6_kernel<3><<<grid, 256, 0, s>>>(k, dww, dwbp, bpi, bmul, dbmul, g);
+    if (k.KB <= 1) pi_gate_x6_kernel<1><<<grid, 256, 0, s>>>(k, dw_gate, dwbp, bpi, bmul, dbmul, g);
+    else if (k.KB == 2) pi_gate_x6_kernel<2><<<grid, 256, 0, s>>>(k, dw_gate, dwbp, bpi, bmul, dbmul, g);
+    else pi_gate_x6_kernel<3><<<grid, 256, 0, s>>>(k, dw_gate, dwbp, bpi, bmul, dbmul, g);
     return bem_check_launch("pi_gate_x6");
 }

@@ -621,7 +621,8 @@ def test_pi_gate_vs_unfused_chain(ops, cfg):
     bd = 0.2 * torch.randn(2 * Hd, generator=g) if bias else None
     perm = ops.gate_order(Hd, "cpu")
     Wg = ops.pack_pw_weight(dev(wi[perm].contiguous()), x6=True)
-    y = ops.pi_gate(dev(x), dev(lw), dev(lb), 1e-6, Wg, None if bi is None else dev(bi[perm].contiguous()), dev(wd), None if bd is None else dev(bd), Hd)
+    wdg, bdg = ops.dw_gate_params(dev(wd), None if bd is None else dev(bd), Hd)
+    y = ops.pi_gate(dev(x), dev(lw), dev(lb), 1e-6, Wg, None if bi is None else dev(bi[perm].contiguous()), wdg, bdg, Hd)
     t = ops.pw_gemm(dev(x), ops.pack_pw_weight(dev(wi), x6=True), 2 * Hd, ln=(dev(lw), dev(lb)), ln_eps=1e-6, bias=None if bi is None else dev(bi))
     chain = ops.dwconv3x3(t, dev(wd), None if bd is None else dev(bd), 2)
     close(y, chain, 1e-4, 2e-5, f"pi_gate vs chain {cfg}")
