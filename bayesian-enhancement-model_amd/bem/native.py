@@ -129,6 +129,8 @@ SIGNATURES = {
     "bem_ln_fwd_f32": [P, P, P, P, F, P, I, I, I64, P],
     "bem_dwact_bwd_f32": [P, P, P, P, P, P, P, I, I, I, I, I, P],
     "bem_pw_wgrad_f32": [ctypes.POINTER(WgradArgs), P],
+    "bem_pw_wgrad_x6_f32": [ctypes.POINTER(WgradArgs), P, I64, P],
+    "bem_pw_wgrad_x6_ws_elems": [I, I, I, I],
     "bem_conv_wgrad_f32": [P, P, I64, P, P, I, I, I, I, I, I, I, I, I, P],
     "bem_ss2d_scan_bwd_f32": [P] * 18 + [I, I, I, I, I64, I64, P],
     "bem_grad_sumsq_f32": [P, I64, P, P],
@@ -136,7 +138,8 @@ SIGNATURES = {
     "bem_last_error": [],
     "bem_abi_version": [],
 }
-_RESTYPE = {"bem_last_error": ctypes.c_char_p, "bem_pw_packed_elems": c_int64, "bem_pw_x6_packed_elems": c_int64, "bem_selective_scan_bwd_ws_elems": c_int64}
+_RESTYPE = {"bem_last_error": ctypes.c_char_p, "bem_pw_packed_elems": c_int64, "bem_pw_x6_packed_elems": c_int64, "bem_selective_scan_bwd_ws_elems": c_int64,
+            "bem_pw_wgrad_x6_ws_elems": c_int64}
 
 _lib = None
 

@@ -6,6 +6,7 @@ launches on torch's current stream.  No wrapper computes anything itself."""
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -1014,6 +1015,10 @@ def dwact_bwd(t, w, bias, dout, dw, dbias, mode):
     return dpre
 
 
+WGRAD_X6 = os.environ.get("BEM_WGRAD_X6", "1") != "0"      # 1x1 weight gradients on the bf16 matrix cores (no LDS transposes) when L % 32 == 0
+_WGX_WS = {}                                               # per-device scratch of the x6 weight-gradient kernel (stream-ordered reuse)
+
+
 def pw_wgrad_(dy, x1, dw, x2=None, dbias=None, blk_rows=0, perm=(0, 1, 2, 3), dy_bstride=0, M=None):
     """dw (M, C1 + C2) += dy . cat(x1, x2)^T over batch and pixels; dbias (M) += row sums of dy.
     dy may be a channel slice of a wider tensor (pass M and dy_bstride)."""
@@ -1039,7 +1044,14 @@ def pw_wgrad_(dy, x1, dw, x2=None, dbias=None, blk_rows=0, perm=(0, 1, 2, 3), dy
         a.perm[i] = perm[i]
     a.dbias = dbias.data_ptr() if dbias is not None else 0
     a.B, a.L = B, L
-    check(lib().bem_pw_wgrad_f32(ctypes.byref(a), _stream()), "pw_wgrad")
+    if WGRAD_X6 and USE_X6 and L % 32 == 0:
+        n = lib().bem_pw_wgrad_x6_ws_elems(M, C1 + C2, B, L)
+        ws = _WGX_WS.get(dw.device)
+        if ws is None or ws.numel() < n:
+            ws = _WGX_WS[dw.device] = torch.empty(max(n, 1 << 20), device=dw.device, dtype=torch.float32)
+        check(lib().bem_pw_wgrad_x6_f32(ctypes.byref(a), _p(ws), ws.numel(), _stream()), "pw_wgrad_x6")
+    else:
+        check(lib().bem_pw_wgrad_f32(ctypes.byref(a), _stream()), "pw_wgrad")
     return dw
 
 

@@ -239,7 +239,7 @@ extern "C" int bem_pw_wgrad_f32(const bem_wgrad_args* a, void* stream) {
     k.B = a->B; k.M = a->M; k.N = N; k.L = a->L;
     if (((k.L & 3) == 0)) {
         BEM_REQUIRE((k.a_bs & 3) == 0 && (k.b1_bs & 3) == 0 && (k.b2_bs & 3) == 0 && ((uintptr_t)k.a & 15) == 0 && ((uintptr_t)k.b1 & 15) == 0 &&
-                    ((uintptr_t)k.b2 & 15) == 0, "pw_wgrad: 16-byte aligned operands / strides expected when L % 4 == 0");
+                    ((uintptr_t)k.b2 & 15) == 0, "pw_wgrad: 16-byte aligned operands / strides expected when L %% 4 == 0");
     }
     return dispatch_wgrad(k, (hipStream_t)stream);
 }

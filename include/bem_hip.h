@@ -368,6 +368,12 @@ typedef struct {
     int B; int L;
 } bem_wgrad_args;
 int bem_pw_wgrad_f32(const bem_wgrad_args* a, void* stream);
+/* The same contract for L % 32 == 0 on the bf16 matrix cores: both operands are loaded in MFMA operand order straight from their
+ * channel planes (consecutive pixels per lane), split into three bf16 limbs and multiplied as six exact limb products with f32
+ * accumulation (the arithmetic of bem_pw_gemm_x6_f32) -- no LDS transposes.  ws: scratch of at least
+ * bem_pw_wgrad_x6_ws_elems(M, C1 + C2, B, L) floats (per-workgroup partial tiles, summed by a second kernel: no float atomics). */
+int64_t bem_pw_wgrad_x6_ws_elems(int M, int K, int B, int L);
+int bem_pw_wgrad_x6_f32(const bem_wgrad_args* a, float* ws, int64_t ws_elems, void* stream);
 /* Weight (+ bias) gradient of the dense convolution of bem_conv2d_f32: dw (Cout,Cin,KH,KW) += dy (*) x, rows gathered on the
  * fly (no im2col tensor); dy (B,Cout,Ho,Wo) contiguous, x (B,Cin,H,W) with batch stride x_bstride (0 = contiguous). */
 int bem_conv_wgrad_f32(const float* dy, const float* x, int64_t x_bstride, float* dw, float* dbias, int B, int Cin, int H, int W,

@@ -140,8 +140,10 @@ def test_dwact_bwd(dev, shape, mode, bias):
 
 
 @pytest.mark.parametrize("B,M,C1,C2,L", [(2, 40, 40, 0, 192), (1, 320, 40, 0, 1024), (2, 20, 40, 0, 77), (3, 80, 80, 80, 130), (1, 640, 160, 0, 64),
-                                         (2, 33, 7, 0, 31), (1, 160, 320, 0, 100), (2, 16, 64, 0, 256)])
+                                         (2, 33, 7, 0, 31), (1, 160, 320, 0, 100), (2, 16, 64, 0, 256), (3, 80, 80, 80, 144), (4, 320, 40, 0, 4096),
+                                         (2, 40, 160, 0, 1024), (5, 7, 33, 0, 16)])
 def test_pw_wgrad(dev, B, M, C1, C2, L):
+    """L % 16 == 0 runs bem_pw_wgrad_x6_f32 (operands straight into the bf16 matrix cores), other sizes bem_pw_wgrad_f32."""
     from bem import ops
     g = G(5)
     dy = torch.randn(B, M, L, generator=g)
