@@ -1146,7 +1146,7 @@ _KEYS = {
     "ss2d_scan": ("ss2d_scan", "hbm", "ss2d_scan_kernel", None),
     "transpose_planes": ("transpose_planes", "hbm", "transpose_planes_kernel", None),
     # training step (bench.py --config train)
-    "pw_wgrad": ("pw_wgrad_", "hbm", "wgrad_kernel<*> (1x1 weight gradients)", None),
+    "pw_wgrad": ("pw_wgrad_", "hbm", "wgrad_x6_kernel<2, 2> + wgrad_x6_reduce_kernel (1x1 weight gradients; wgrad_kernel<*> for L % 32 != 0)", None),
     "conv_wgrad": ("conv_wgrad_", "mfma", "wgrad_kernel<*> (dense conv weight gradients)", None),
     "ss2d_scan_bwd": ("ss2d_scan_bwd", "hbm", "ss2d_scan_bwd_kernel", None),
     "dwact_bwd": ("dwact_bwd", "hbm", "dwact_bwd_kernel", None),

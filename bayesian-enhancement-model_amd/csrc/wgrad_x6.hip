@@ -11,9 +11,9 @@
 // Mapping: a wave walks over 32-pixel chunks (two MFMA K-steps), in runs of consecutive chunks strided over all waves of grid.x;
 // grid.y / grid.z select a group of MTW M-tiles (dy rows) and NTW N-tiles (x rows).  Per chunk a lane loads 64 contiguous bytes of
 // its dy row and of its x row per tile -- a half-wave pair covers one full 128-byte line per row -- one chunk ahead of the
-// arithmetic (double-buffered in registers; the kernel takes a SIMD's whole register file, one wave per SIMD).  The four waves
-// of a workgroup add their accumulators in LDS, the workgroup stores its partial tile to its workspace slot and a second small
-// kernel sums the slots into dW (16 adders per element): with float atomics the few hundred output lines were the bottleneck (130 of 380 us).
+// arithmetic (triple-buffered in registers; the kernel takes a SIMD's whole register file, one wave per SIMD).  The four waves
+// of a workgroup walk the same chunks and own different tile groups (shared operand rows come from L1 / L2); every wave stores
+// its partial tiles to the workgroup row's workspace slot and a second small kernel sums the slots into dW (16 adders per element): with float atomics the few hundred output lines were the bottleneck (130 of 380 us).
 #include "bem_common.h"
 #include "x6_common.h"
 #include <stdlib.h>
@@ -29,16 +29,19 @@ struct WxK {
     float* dbias;
     int L, K, MT, NT, cpi, nq;        // cpi = chunks per image (L / 32), nq = B * cpi
     float* ws; int64_t slot_elems;    // workspace: grid.x slots of M * K (+ M) partial sums
+    int wy, wz;                       // waves of a workgroup: wy M-tile groups x wz N-tile groups (wy * wz <= 4)
 };
 
 template <int MTW, int NTW>
 __global__ __launch_bounds__(256, 1) void wgrad_x6_kernel(WxK k) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kh = lane >> 5, n = lane & 31;
-    const int mt0 = blockIdx.y * MTW, nt0 = blockIdx.z * NTW;
-    __shared__ float red[MTW * 32][NTW * 32 + 1];
-    __shared__ float rsum[MTW * 32];
-    for (int i = threadIdx.x; i < MTW * 32 * (NTW * 32 + 1); i += 256) (&red[0][0])[i] = 0.f;
-    for (int i = threadIdx.x; i < MTW * 32; i += 256) rsum[i] = 0.f;
+    // the four waves of a workgroup walk the SAME pixel chunks and own different tile groups (k.wy x k.wz of them): the operand a
+    // group shares with its neighbour comes out of the CU's L1 / the XCD's L2, so HBM sees dy and x about once
+    // (with fewer than four tile groups the spare waves take chunk runs of their own: sub-rows of the workgroup, one slot each)
+    const int ng = k.wy * k.wz, grp = wave % ng, sub = wave / ng, nsub = 4 / ng;
+    const int wyi = grp % k.wy, wzi = grp / k.wy;
+    const int mt0 = (blockIdx.y * k.wy + wyi) * MTW, nt0 = (blockIdx.z * k.wz + wzi) * NTW;
+    if (mt0 >= k.MT || nt0 >= k.NT || sub >= nsub) return;       // no barrier below: idle waves may leave
 
     // K mapping inside a 32-pixel chunk: lanes 0-31 (kh = 0) own pixels 0..15 of their row, lanes 32-63 pixels 16..31 -- one full
     // 128-byte line per row and load group.  MFMA 0 of the chunk multiplies pixels {0..7, 16..23}, MFMA 1 pixels {8..15, 24..31};
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_x6_kernel(WxK k) {
     // a wave takes runs of RUN consecutive chunks (RUN * 128 bytes of every row), runs strided over all waves of grid.x; one chunk
     // (64 registers of raw operands) is always in flight under the arithmetic of the current one
     constexpr int RUN = 4;
-    const int nwave = gridDim.x * 4, w0 = blockIdx.x * 4 + wave;
+    const int nwave = gridDim.x * nsub, w0 = blockIdx.x * nsub + sub;
     auto load = [&](int qq, float4 (&ra)[MTW][4], float4 (&rb)[NTW][4]) {
         const int b = qq / k.cpi, p0 = (qq - b * k.cpi) * 32;
 #pragma unroll
@@ -141,32 +144,28 @@ __global__ __launch_bounds__(256, 1) void wgrad_x6_kernel(WxK k) {
         compute(ra2, rb2);
         q = q3; q1 = q4;
     }
-    __syncthreads();                                             // red / rsum zeroed
+    // this wave's partial tiles go to the workgroup row's slot of the workspace (plain stores: 128 contiguous bytes per accumulator
+    // row); wgrad_x6_reduce_kernel sums the slots into dW
+    float* slot = k.ws + (int64_t)w0 * k.slot_elems;
 #pragma unroll
     for (int m = 0; m < MTW; ++m)
 #pragma unroll
-        for (int t = 0; t < NTW; ++t)
+        for (int t = 0; t < NTW; ++t) {
+            const int gc = (nt0 + t) * 32 + n;
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                atomicAdd(&red[m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh][t * 32 + n], acc[m][t][r] + alo[m][t][r]);
-    if (k.dbias && blockIdx.z == 0) {
+            for (int r = 0; r < 16; ++r) {
+                const int gm = (mt0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (gm < k.M && gc < k.K) slot[(int64_t)gm * k.K + gc] = acc[m][t][r] + alo[m][t][r];
+            }
+        }
+    if (k.dbias && nt0 == 0) {
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
-            const float s = rs[m] + __shfl_xor(rs[m], 32, 64);
-            if (kh == 0) atomicAdd(&rsum[m * 32 + n], s);
+            const float sm = rs[m] + __shfl_xor(rs[m], 32, 64);
+            const int gm = (mt0 + m) * 32 + n;
+            if (kh == 0 && gm < k.M) slot[(int64_t)k.M * k.K + gm] = sm;
         }
     }
-    __syncthreads();
-    // the workgroup's partial tile goes to its own slot of the workspace (plain stores); wgrad_x6_reduce_kernel sums the slots
-    float* slot = k.ws + (int64_t)blockIdx.x * k.slot_elems;
-    for (int i = threadIdx.x; i < MTW * 32 * NTW * 32; i += 256) {
-        const int row = i / (NTW * 32), col = i - row * (NTW * 32);
-        const int gm = mt0 * 32 + row, gc = nt0 * 32 + col;
-        if (gm < k.M && gc < k.K) slot[(int64_t)gm * k.K + gc] = red[row][col];
-    }
-    if (k.dbias && blockIdx.z == 0)
-        for (int i = threadIdx.x; i < MTW * 32; i += 256)
-            if (mt0 * 32 + i < k.M) slot[(int64_t)k.M * k.K + mt0 * 32 + i] = rsum[i];
 }
 
 // dW[row map(m)][c] += sum over the gx slots; dbias likewise.  grid (elements / 256, slot groups): a thread sums its group's slots
@@ -198,19 +197,25 @@ __global__ void wgrad_x6_reduce_kernel(WxK k, int gx) {
 
 }  // namespace
 
-static int wgx_grid_x(int M, int K, int B, int L) {
-    const int gy = cdiv(cdiv(M, 32), 2), gz = cdiv(cdiv(K, 32), 2);
+struct WgxGrid { int gx, gy, gz, wy, wz, nslot; };
+static WgxGrid wgx_grid(int M, int K, int B, int L) {
+    const int py = cdiv(cdiv(M, 32), 2), pz = cdiv(cdiv(K, 32), 2);          // tile groups (2 x 2 tiles each) along M and along K
+    WgxGrid g;
+    g.wy = std::min(4, py);
+    g.wz = std::min(4 / g.wy, pz);
+    g.gy = cdiv(py, g.wy); g.gz = cdiv(pz, g.wz);
     const int64_t nq = (int64_t)B * (L / 32);
-    // one 4-wave workgroup per CU (the kernel takes the whole register file of a SIMD): ~512 workgroups in all, every wave at least
-    // two runs of chunks
-    int gx = std::max(1, 512 / (gy * gz));
-    gx = (int)std::min<int64_t>(gx, std::max<int64_t>(1, nq / 32));
-    return gx;
+    // one workgroup per CU (a wave takes a SIMD's whole register file): ~512 workgroups in all, each at least two runs of 4 chunks
+    g.gx = std::max(1, 512 / (g.gy * g.gz));
+    const int nsub = 4 / (g.wy * g.wz);
+    g.gx = (int)std::min<int64_t>(g.gx, std::max<int64_t>(1, nq / (8 * nsub)));
+    g.nslot = g.gx * nsub;
+    return g;
 }
 
 extern "C" int64_t bem_pw_wgrad_x6_ws_elems(int M, int K, int B, int L) {
     if (M <= 0 || K <= 0 || B <= 0 || L <= 0) return 0;
-    return (int64_t)wgx_grid_x(M, K, B, L) * ((int64_t)M * K + M);
+    return (int64_t)wgx_grid(M, K, B, L).nslot * ((int64_t)M * K + M);
 }
 
 extern "C" int bem_pw_wgrad_x6_f32(const bem_wgrad_args* a, float* ws, int64_t ws_elems, void* stream) {
@@ -237,12 +242,14 @@ extern "C" int bem_pw_wgrad_x6_f32(const bem_wgrad_args* a, float* ws, int64_t w
     const int64_t nq = (int64_t)a->B * k.cpi;
     BEM_REQUIRE(nq < (1ll << 31), "pw_wgrad_x6: too many pixel chunks");
     k.nq = (int)nq;
-    const int gy = cdiv(k.MT, 2), gz = cdiv(k.NT, 2), gx = wgx_grid_x(a->M, k.K, a->B, a->L);
+    const WgxGrid gg = wgx_grid(a->M, k.K, a->B, a->L);
+    const int gx = gg.nslot;          // slots to sum
+    k.wy = gg.wy; k.wz = gg.wz;
     k.ws = ws; k.slot_elems = (int64_t)a->M * k.K + a->M;
     BEM_REQUIRE(ws_elems >= (int64_t)gx * k.slot_elems, "pw_wgrad_x6: workspace of %lld floats, bem_pw_wgrad_x6_ws_elems asks for %lld",
                 (long long)ws_elems, (long long)((int64_t)gx * k.slot_elems));
     hipStream_t st = (hipStream_t)stream;
-    wgrad_x6_kernel<2, 2><<<dim3(gx, gy, gz), 256, 0, st>>>(k);
+    wgrad_x6_kernel<2, 2><<<dim3(gg.gx, gg.gy, gg.gz), 256, 0, st>>>(k);
     const int64_t tot = (int64_t)a->M * k.K + (a->dbias ? a->M : 0);
     wgrad_x6_reduce_kernel<<<dim3((unsigned)cdiv64(tot, 256), std::min(gx, 16)), 256, 0, st>>>(k, gx);
     return bem_check_launch("pw_wgrad_x6");

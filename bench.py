@@ -223,7 +223,7 @@ def main():
                "dtype": "f32", "data": "synthetic"}
         if train:
             out["metric"] = f"images/sec (whole node) DecompDualBranchDDWavelet Stage-II training step (fwd+bwd+AdamW) @{S}x{S}"
-            out["arithmetic"] = "f32 storage and accumulation; forward / input-gradient 1x1 GEMMs as exact 3-limb bf16 expansions, weight gradients on f32 MFMA"
+            out["arithmetic"] = "f32 storage and accumulation; forward, input-gradient and weight-gradient 1x1 GEMMs as exact 3-limb bf16 expansions (6 MFMA products), conv weight gradients on f32 MFMA"
             out["config"] = {"workload": f"DecompDualBranch2DDWavelet_4.yml training step (fwd+bwd+clip+AdamW), batch={B} {S}x{S} per GPU, L1 loss",
                              "images_per_gpu": B, "parallelism": f"replicas x{world} (no gradient all-reduce: BASELINE config 4 is single-GPU)"}
             bytes_img = 3.0 * BYTES_STAGE2_PER_PIXEL * S * S          # fwd + 2x for bwd on the same tensors

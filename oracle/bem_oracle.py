@@ -595,7 +595,7 @@ def train_step_ref(sd: SD, lq, gt, conds, *, stage2=ddwavelet_ref, scale=16, lr=
         else:
             gn = torch.sqrt(sum((p.grad ** 2).sum() for p in params.values()))
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
         norms.append(float(gn))
     return dict(loss=losses, grad_norm=norms, grads=grads0, params={k: v.detach() for k, v in params.items()}, out=out.detach())
 
