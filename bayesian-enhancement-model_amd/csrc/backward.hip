@@ -330,7 +330,7 @@ __device__ __forceinline__ void dw_window(const float* __restrict__ plane, int H
         const bool rowok = yy >= 0 && yy < H;
         const float* r = plane + (int64_t)(rowok ? yy : 0) * W;
         const float m = rowok ? 1.f : 0.f;
-        v[ry + 1][0] = (x0 > 0 ? r[x0 - 1] : 0.f) * m;
+        v[ry + 1][0] = r[max(x0 - 1, 0)] * (x0 > 0 ? m : 0.f);               // clamped address + mask: no branch next to the load
         if (vec) {
             const float4 c = *reinterpret_cast<const float4*>(r + x0);
             v[ry + 1][1] = c.x * m; v[ry + 1][2] = c.y * m; v[ry + 1][3] = c.z * m; v[ry + 1][4] = c.w * m;
@@ -338,7 +338,7 @@ __device__ __forceinline__ void dw_window(const float* __restrict__ plane, int H
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[ry + 1][1 + i] = ((x0 + i < W) ? r[x0 + i] : 0.f) * m;
         }
-        v[ry + 1][5] = ((x0 + 4 < W) ? r[x0 + 4] : 0.f) * m;
+        v[ry + 1][5] = r[min(x0 + 4, W - 1)] * (x0 + 4 < W ? m : 0.f);
     }
 }
 __device__ __forceinline__ void dw_apply(const float (&v)[RBB + 2][6], const float* __restrict__ w9, float bias, float (&pre)[RBB][4]) {
@@ -371,7 +371,7 @@ __device__ __forceinline__ void dw_corr(const float (&v)[RBB + 2][6], const floa
         }
 }
 
-template <int MODE>
+template <int MODE, bool VEC>
 __global__ __launch_bounds__(256) void dwact_bwd_kernel(const float* __restrict__ t, const float* __restrict__ w, const float* __restrict__ bias,
                                                         const float* __restrict__ dout, float* __restrict__ dpre, float* __restrict__ dw,
                                                         float* __restrict__ dbias, int Cout, int H, int W) {
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void dwact_bwd_kernel(const float* __restrict_
     const int c = blockIdx.y, b = blockIdx.z;
     const int Cin = (MODE == 2) ? 2 * Cout : Cout;
     const int64_t HW = (int64_t)H * W;
-    const bool vec = (W & 3) == 0;
+    constexpr bool vec = VEC;                                   // W % 4 == 0, a compile-time variant: no per-row branches around the loads
     float s0[10], s1[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) s0[k] = s1[k] = 0.f;
@@ -394,12 +394,20 @@ __global__ __launch_bounds__(256) void dwact_bwd_kernel(const float* __restrict_
         dw_apply(v0, w + (int64_t)c * 9, bias ? bias[c] : 0.f, pre0);
         const float* gp = dout + ((int64_t)b * Cout + c) * HW;
 #pragma unroll
-        for (int oy = 0; oy < RBB; ++oy)
+        for (int oy = 0; oy < RBB; ++oy) {
+            if (vec) {                                          // W % 4 == 0: the four columns are in range together, one 16-byte load
+                const int yc = min(y0 + oy, H - 1);
+                const float4 q = *reinterpret_cast<const float4*>(gp + (int64_t)yc * W + x0);
+                const float mk = (active && y0 + oy < H) ? 1.f : 0.f;
+                g[oy][0] = q.x * mk; g[oy][1] = q.y * mk; g[oy][2] = q.z * mk; g[oy][3] = q.w * mk;
+            } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool ok = active && (y0 + oy < H) && (x0 + j < W);
-                g[oy][j] = ok ? gp[(int64_t)(y0 + oy) * W + x0 + j] : 0.f;
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = active && (y0 + oy < H) && (x0 + j < W);
+                    g[oy][j] = ok ? gp[(int64_t)(y0 + oy) * W + x0 + j] : 0.f;
+                }
             }
+        }
         if (MODE == 2) {
             float v1[RBB + 2][6], pre1[RBB][4], d1[RBB][4];
             dw_window(t + ((int64_t)b * Cin + c + Cout) * HW, H, W, y0, x0, vec, v1);
@@ -409,18 +417,24 @@ __global__ __launch_bounds__(256) void dwact_bwd_kernel(const float* __restrict_
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float h1 = pre0[oy][j], h2 = pre1[oy][j];
-                    const float cdf = 0.5f * (1.f + erff(h1 * 0.70710678118654752440f));
-                    const float pdf = 0.3989422804014327f * __expf(-0.5f * h1 * h1);
+                    // erf by Abramowitz-Stegun 7.1.26 on the hardware rcp / exp (|error| <= 1.5e-7, bem_common.h) instead of libm's branchy erff
+                    const float cdf = 0.5f * (1.f + bem_erf_fast(h1 * 0.70710678118654752440f));
+                    const float pdf = 0.3989422804014327f * bem_fexp(-0.5f * h1 * h1);
                     d0[oy][j] = g[oy][j] * h2 * (cdf + h1 * pdf);
                     d1[oy][j] = g[oy][j] * h1 * cdf;
                 }
             dw_corr(v1, d1, s1);
             float* o1 = dpre + ((int64_t)b * Cin + c + Cout) * HW;
 #pragma unroll
-            for (int oy = 0; oy < RBB; ++oy)
+            for (int oy = 0; oy < RBB; ++oy) {
+                if (vec) {
+                    if (active && y0 + oy < H) *reinterpret_cast<float4*>(o1 + (int64_t)(y0 + oy) * W + x0) = make_float4(d1[oy][0], d1[oy][1], d1[oy][2], d1[oy][3]);
+                } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (active && y0 + oy < H && x0 + j < W) o1[(int64_t)(y0 + oy) * W + x0 + j] = d1[oy][j];
+                    for (int j = 0; j < 4; ++j)
+                        if (active && y0 + oy < H && x0 + j < W) o1[(int64_t)(y0 + oy) * W + x0 + j] = d1[oy][j];
+                }
+            }
         } else {
 #pragma unroll
             for (int oy = 0; oy < RBB; ++oy)
@@ -438,10 +452,15 @@ __global__ __launch_bounds__(256) void dwact_bwd_kernel(const float* __restrict_
         dw_corr(v0, d0, s0);
         float* o0 = dpre + ((int64_t)b * Cin + c) * HW;
 #pragma unroll
-        for (int oy = 0; oy < RBB; ++oy)
+        for (int oy = 0; oy < RBB; ++oy) {
+            if (vec) {
+                if (active && y0 + oy < H) *reinterpret_cast<float4*>(o0 + (int64_t)(y0 + oy) * W + x0) = make_float4(d0[oy][0], d0[oy][1], d0[oy][2], d0[oy][3]);
+            } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (active && y0 + oy < H && x0 + j < W) o0[(int64_t)(y0 + oy) * W + x0 + j] = d0[oy][j];
+                for (int j = 0; j < 4; ++j)
+                    if (active && y0 + oy < H && x0 + j < W) o0[(int64_t)(y0 + oy) * W + x0 + j] = d0[oy][j];
+            }
+        }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -587,9 +606,16 @@ extern "C" int bem_dwact_bwd_f32(const float* t, const float* w, const float* bi
     const int W4 = (W + 3) >> 2, HB = (H + RBB - 1) / RBB;
     const dim3 grid((unsigned)cdiv(HB * W4, 256), (unsigned)Cout, (unsigned)B);
     hipStream_t s = (hipStream_t)stream;
-    if (mode == 2) dwact_bwd_kernel<2><<<grid, 256, 0, s>>>(t, w, bias, dout, dpre, dw, dbias, Cout, H, W);
-    else if (mode == 1) dwact_bwd_kernel<1><<<grid, 256, 0, s>>>(t, w, bias, dout, dpre, dw, dbias, Cout, H, W);
-    else dwact_bwd_kernel<0><<<grid, 256, 0, s>>>(t, w, bias, dout, dpre, dw, dbias, Cout, H, W);
+    const bool vec = (W & 3) == 0 && ((uintptr_t)t & 15) == 0 && ((uintptr_t)dout & 15) == 0 && ((uintptr_t)dpre & 15) == 0;
+#define BEM_DWACT(M)                                                                                             \
+    do {                                                                                                         \
+        if (vec) dwact_bwd_kernel<M, true><<<grid, 256, 0, s>>>(t, w, bias, dout, dpre, dw, dbias, Cout, H, W);  \
+        else dwact_bwd_kernel<M, false><<<grid, 256, 0, s>>>(t, w, bias, dout, dpre, dw, dbias, Cout, H, W);     \
+    } while (0)
+    if (mode == 2) BEM_DWACT(2);
+    else if (mode == 1) BEM_DWACT(1);
+    else BEM_DWACT(0);
+#undef BEM_DWACT
     return bem_check_launch("dwact_bwd");
 }
 
