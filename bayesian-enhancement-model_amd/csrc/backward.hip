@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
 // Faster form for C <= 160: the four wavefronts of a workgroup split the channels of the same 64 pixels (CPT = ceil(C / 4) each),
 // x and dn are read ONCE into registers (all loads of a tile issue back to back), the per-pixel statistics are combined through
 // LDS (two barriers per tile), dgamma / dbeta accumulate in registers over the workgroup's tiles (one atomic per channel at the end).
-template <int CPT, int NWV>
+template <int CPT, int NWV, bool X2, bool DRES, bool NOUT>
 __global__ __launch_bounds__(64 * NWV) void ln_bwd_split_kernel(const float* __restrict__ x1, const float* __restrict__ x2, const float* __restrict__ dn,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                                 const float* __restrict__ dres, float* __restrict__ dx, float* __restrict__ n_out,
@@ -226,12 +226,15 @@ __global__ __launch_bounds__(64 * NWV) void ln_bwd_split_kernel(const float* __r
         float xv[CPT], dv[CPT];
 #pragma unroll
         for (int j = 0; j < CPT; ++j) xv[j] = x1[base + (int64_t)min(c0 + j, C - 1) * L];
-        if (x2) {
+        if (X2) {                                           // compile-time variants: no branch sits between the loads of a tile
 #pragma unroll
             for (int j = 0; j < CPT; ++j) xv[j] += x2[base + (int64_t)min(c0 + j, C - 1) * L];
         }
 #pragma unroll
         for (int j = 0; j < CPT; ++j) dv[j] = dn[base + (int64_t)min(c0 + j, C - 1) * L];
+        float rv[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) rv[j] = DRES ? dres[base + (int64_t)min(c0 + j, C - 1) * L] : 0.f;
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < CPT; ++j) s += (c0 + j < C) ? xv[j] : 0.f;
@@ -268,10 +271,10 @@ __global__ __launch_bounds__(64 * NWV) void ln_bwd_split_kernel(const float* __r
             const float xh = xv[j] * rstd;
             float r = rstd * (dv[j] * gm - s1 - xh * s2);
             const int64_t idx = base + (int64_t)c * L;
-            if (dres) r += dres[idx];
+            r += rv[j];
             if (ok && c0 + j < C) {
                 dx[idx] = r;
-                if (n_out) n_out[idx] = fmaf(xh, gm, beta[c]);
+                if (NOUT) n_out[idx] = fmaf(xh, gm, beta[c]);
             }
             ag[j] = fmaf(dv[j] * okm, xh, ag[j]);
             ab[j] = fmaf(dv[j], okm, ab[j]);
@@ -573,12 +576,27 @@ extern "C" int bem_ln_bwd_f32(const float* x1, const float* x2, const float* dn,
         const int64_t tpi = cdiv64(L, 64), total = tpi * B;
         const int tpw = (int)std::max<int64_t>(1, cdiv64(total, 1024));
         const unsigned grid = (unsigned)cdiv64(total, tpw);
-#define BEM_LNB(CPT, NWV) ln_bwd_split_kernel<CPT, NWV><<<grid, 64 * NWV, 0, s>>>(x1, x2, dn, gamma, beta, eps, dres, dx, n_out, dgamma, dbeta, C, L, tpi, total, tpw)
+#define BEM_LNB3(CPT, NWV, A, D, N) ln_bwd_split_kernel<CPT, NWV, A, D, N><<<grid, 64 * NWV, 0, s>>>(x1, x2, dn, gamma, beta, eps, dres, dx, n_out, dgamma, dbeta, C, L, tpi, total, tpw)
+#define BEM_LNB(CPT, NWV)                                                                                        \
+    do {                                                                                                         \
+        const int v = (x2 ? 4 : 0) | (dres ? 2 : 0) | (n_out ? 1 : 0);                                           \
+        switch (v) {                                                                                             \
+            case 0: BEM_LNB3(CPT, NWV, false, false, false); break;                                              \
+            case 1: BEM_LNB3(CPT, NWV, false, false, true); break;                                               \
+            case 2: BEM_LNB3(CPT, NWV, false, true, false); break;                                               \
+            case 3: BEM_LNB3(CPT, NWV, false, true, true); break;                                                \
+            case 4: BEM_LNB3(CPT, NWV, true, false, false); break;                                               \
+            case 5: BEM_LNB3(CPT, NWV, true, false, true); break;                                                \
+            case 6: BEM_LNB3(CPT, NWV, true, true, false); break;                                                \
+            default: BEM_LNB3(CPT, NWV, true, true, true); break;                                                \
+        }                                                                                                        \
+    } while (0)
         if (C <= 16) BEM_LNB(4, 4);
         else if (C <= 40) BEM_LNB(10, 4);
         else if (C <= 80) BEM_LNB(10, 8);
         else BEM_LNB(20, 8);
 #undef BEM_LNB
+#undef BEM_LNB3
         return bem_check_launch("ln_bwd");
     }
     const int64_t tiles = cdiv64(L, 256);
