@@ -44,7 +44,7 @@ class _Cache:
 # pixel per lane -- 189 vs 232 img/s end to end -- so off by default
 GATE_PROJ = __import__("os").environ.get("BEM_GATE_PROJ", "0") != "0"
 SCAN_RM = os.environ.get("BEM_SCAN_RM", "1") != "0"          # row-major SS2D scan (no transposes of xc / y1) where the plane size allows
-PI_GATE = os.environ.get("BEM_PI_GATE", "1") != "0"          # project_in + depthwise 3x3 + gate in one kernel where it applies (C <= 48)
+PI_GATE = os.environ.get("BEM_PI_GATE", "1") != "0"          # project_in + depthwise 3x3 + gate in one kernel where it applies (C <= ops.PI_GATE_MAXC = 48)
 FUSE_GDMLP = os.environ.get("BEM_FUSE_GDMLP", "0") != "0"    # 0: unfused three-kernel gdMlp (kept for A/B checks)
 
 
@@ -424,7 +424,7 @@ class gdMlp(nn.Module):
             Wpi, bpi, dww, dwb, Wpo, bpo = self._fused_params(B)
             return ops.gdmlp_fused(x, norm.weight.detach(), norm.bias.detach(), norm.eps, Wpi, bpi, dww, dwb, Wpo, bpo, Hd)
         if PI_GATE and isinstance(self.project_in, PwConv2d) and isinstance(self.dwconv, DwConv2d) and ops.pi_gate_supported(C, Hd):
-            # the 2Hd-channel project_in output lives only in LDS (bem_pi_gate_x6_f32); deterministic weights, C <= 48
+            # the 2Hd-channel project_in output lives only in LDS (bem_pi_gate_x6_f32); deterministic weights, C <= ops.PI_GATE_MAXC
             pi, dw = self.project_in, self.dwconv
 
             def prep():

@@ -316,8 +316,13 @@ def gate_order(Hd, device):
     return torch.cat([16 * j + r, Hd + 16 * j + r], 1).reshape(-1)
 
 
+# widest input the fused gdMlp front half is used for.  The kernel takes C <= 80, but its 8-wave / 4-row form for C > 48 (one workgroup
+# per CU) measured 503 us against 146 + 145 us for the two-kernel chain at the bench's level 1 (C = 80, 64 x 64 planes): default 48
+PI_GATE_MAXC = int(os.environ.get("BEM_PI_GATE_MAXC", "48"))
+
+
 def pi_gate_supported(C, Hd):
-    return USE_X6 and C <= 48 and Hd % 16 == 0
+    return USE_X6 and C <= PI_GATE_MAXC and Hd % 16 == 0
 
 
 def dw_gate_params(dww, dwb, Hd):
@@ -333,7 +338,7 @@ def pi_gate(x, ln_w, ln_b, ln_eps, Wp_gate, bias_gate, dww, dwb, Hd):
     _chk(dww, "dww"); _chk(dwb, "dwb", optional=True)
     B, C, H, W = x.shape
     if not pi_gate_supported(C, Hd):
-        raise ValueError(f"pi_gate: C = {C} (<= 48) / Hd = {Hd} (% 16) not supported")
+        raise ValueError(f"pi_gate: C = {C} (<= {PI_GATE_MAXC}) / Hd = {Hd} (% 16) not supported")
     if tuple(dww.shape) != (Hd, 9, 2) or (dwb is not None and tuple(dwb.shape) != (Hd, 2)):
         raise ValueError("pi_gate: depthwise parameters must come from dw_gate_params")
     if ln_w.numel() != C or ln_b.numel() != C or dww.numel() != 2 * Hd * 9 or (dwb is not None and dwb.numel() != 2 * Hd) \

@@ -33,15 +33,27 @@ struct PgX {
     int C, Hd, H, W, KB, NCH, tx, dbg;
 };
 
-constexpr int PG_TH = 8, PG_TW = 32, PG_HW = PG_TW + 2, PG_NPH = (PG_TH + 2) * PG_HW, PG_NPB = (PG_NPH + 31) / 32;
-constexpr int PG_BPW = (PG_NPB + 3) / 4, PG_TS = PG_NPB * 32;
+// tile geometry: TH x 32 pixels, NW waves.  <8, 4> for C <= 48: 11 halo blocks, three per wave (their limbs fit the register file), a
+// wave owns two rows and all 16 gate channels of a chunk in phase B.  <4, 8> for C <= 80: halo 6 x 34 = 7 blocks, ONE per wave, the
+// chunk's packed weights go through LDS, in phase B a wave owns two rows and four gate channels.
+constexpr int PG_TW = 32, PG_HW = PG_TW + 2;
 
 // dww / dwb / bpi / g are separate __restrict__ arguments (not struct fields) so that the compiler knows the stores to g cannot
 // touch them: the wave-uniform depthwise parameters then come in through scalar loads instead of per-lane vector loads.
-template <int KBM>
-__global__ __launch_bounds__(256, 2) void pi_gate_x6_kernel(PgX k, const float* __restrict__ dww, const float* __restrict__ dwb,
+template <int KBM, int PG_TH, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pi_gate_x6_kernel(PgX k, const float* __restrict__ dww, const float* __restrict__ dwb,
                                                             const float* __restrict__ bpi, float bmul, float dbmul, float* __restrict__ g) {
+    constexpr int NT = 64 * NW;
+    constexpr int PG_NPH = (PG_TH + 2) * PG_HW, PG_NPB = (PG_NPH + 31) / 32, PG_BPW = (PG_NPB + NW - 1) / NW, PG_TS = PG_NPB * 32;
+    constexpr int RG = PG_TH / 2;                         // row pairs of the tile = waves per channel group in phase B
+    constexpr int NCW = 16 / (NW / RG);                   // gate channels of a chunk per wave in phase B
+    static_assert(NW % RG == 0 && 16 % (NW / RG) == 0, "phase-B mapping");
     __shared__ f32x2 T[16 * PG_TS];                       // [gate channel c][halo pixel] = (h1 input, h2 input)
+    // NW == 8 (wide inputs): a chunk's packed weights (KBM x 3 KB) go through LDS once per workgroup (fetched during phase B of the
+    // previous chunk) instead of 3 KBM registers per lane in every wave
+    constexpr bool WLDS = NW == 8;
+    constexpr int WSH_N = WLDS ? KBM * 3 * 64 : 1, WPT = (WSH_N + NT - 1) / NT;
+    __shared__ u32x4 Wsh[WSH_N];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kh = lane >> 5, n = lane & 31;
     const int b = blockIdx.z;
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
@@ -66,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void pi_gate_x6_kernel(PgX k, const float* 
     int hpo[PG_BPW];
 #pragma unroll
     for (int i = 0; i < PG_BPW; ++i) {
-        const int hp = min((wave + 4 * i) * 32 + n, PG_TS - 1);
+        const int hp = min((wave + NW * i) * 32 + n, PG_TS - 1);
         hpo[i] = hp;
         const int hy = hp / PG_HW, hx = hp - hy * PG_HW;
         const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
@@ -111,16 +123,35 @@ __global__ __launch_bounds__(256, 2) void pi_gate_x6_kernel(PgX k, const float* 
 
     const u32x4* wbase = k.Wp + lane;
     const int64_t ch_stride = (int64_t)k.KB * 3 * 64;
-    u32x4 wc[KBM][3];
+    u32x4 wc[WLDS ? 1 : KBM][3];
+    u32x4 wst[WPT];                                       // WLDS: this thread's share of the next chunk's weights on their way to LDS
     float4 bq[4];
+    auto fetch_wsh = [&](int j) {
+#pragma unroll
+        for (int u = 0; u < WPT; ++u) {
+            const int i = min((int)threadIdx.x + NT * u, WSH_N - 1);
+            const int kb = i / 192, rest = i - kb * 192;                   // [kb][limb][lane]
+            const uint32_t mk = kb < k.KB ? 0xffffffffu : 0u;
+            const u32x4 w = k.Wp[(int64_t)j * ch_stride + (int64_t)min(kb, k.KB - 1) * 192 + rest];
+            wst[u] = u32x4{w[0] & mk, w[1] & mk, w[2] & mk, w[3] & mk};
+        }
+    };
+    auto store_wsh = [&]() {
+#pragma unroll
+        for (int u = 0; u < WPT; ++u) {
+            const int i = (int)threadIdx.x + NT * u;
+            if (i < WSH_N) Wsh[i] = wst[u];
+        }
+    };
     auto load_w = [&](int j) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 v = *reinterpret_cast<const float4*>(bpi + 32 * j + 8 * q + 4 * kh);
             bq[q] = make_float4(v.x * bmul, v.y * bmul, v.z * bmul, v.w * bmul);
         }
+        if (WLDS) { fetch_wsh(j); return; }
 #pragma unroll
-        for (int kb = 0; kb < KBM; ++kb) {
+        for (int kb = 0; kb < (WLDS ? 0 : KBM); ++kb) {
             const uint32_t mk = kb < k.KB ? 0xffffffffu : 0u;
             const u32x4* wp = wbase + (int64_t)j * ch_stride + (int64_t)min(kb, k.KB - 1) * 3 * 64;
 #pragma unroll
@@ -131,9 +162,12 @@ __global__ __launch_bounds__(256, 2) void pi_gate_x6_kernel(PgX k, const float* 
         }
     };
     load_w(0);
+    if (WLDS) { store_wsh(); __syncthreads(); }
 
-    // phase-B geometry: output pixel (ry, n) of the tile; its window starts at halo (ry, n)
-    const int ry = 2 * wave + kh;
+    // phase-B geometry: output pixel (ry, n) of the tile; its window starts at halo (ry, n).  Wave w owns the row pair w % RG and the
+    // gate channels NCW (w / RG) .. of every chunk
+    const int ry = (NW == RG) ? 2 * wave + kh : 2 * (wave % RG) + kh;
+    const int c_lo = (NW == RG) ? 0 : NCW * __builtin_amdgcn_readfirstlane(wave / RG);
     const int oy = y0 + ry, ox = x0 + n;
     const bool ost = oy < k.H && ox < k.W;
     const int wbase_lds = ry * PG_HW + n;
@@ -143,12 +177,21 @@ __global__ __launch_bounds__(256, 2) void pi_gate_x6_kernel(PgX k, const float* 
         // ---- phase A
 #pragma unroll
         for (int i = 0; i < PG_BPW; ++i) {
-            if (wave + 4 * i < PG_NPB && !(k.dbg & 1)) {                           // wave-uniform
+            if (wave + NW * i < PG_NPB && !(k.dbg & 1)) {                           // wave-uniform
                 f32x16 hi, lo;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) hi[r] = lo[r] = 0.f;
+                if (WLDS) {
 #pragma unroll
-                for (int kb = 0; kb < KBM; ++kb) mac6(wc[kb], xl[i][kb], hi, lo);
+                    for (int kb = 0; kb < KBM; ++kb) {
+                        const u32x4* wp = Wsh + kb * 192 + lane;
+                        const u32x4 wl[3] = {wp[0], wp[64], wp[128]};
+                        mac6(wl, xl[i][kb], hi, lo);
+                    }
+                } else {
+#pragma unroll
+                    for (int kb = 0; kb < (WLDS ? 0 : KBM); ++kb) mac6(wc[kb], xl[i][kb], hi, lo);
+                }
                 f32x2* tp = T + 4 * kh * PG_TS + hpo[i];
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
@@ -168,9 +211,10 @@ __global__ __launch_bounds__(256, 2) void pi_gate_x6_kernel(PgX k, const float* 
         // ---- phase B: all 16 channel pairs unrolled -- the scalar weight loads, LDS window reads and the exp / rcp chains of
         // different channels are independent, and with two waves per SIMD that ILP is what hides their latencies
         if (!(k.dbg & 2)) {
-            float hg[16], hv[16];
+            float hg[NCW], hv[NCW];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
+            for (int cw = 0; cw < NCW; ++cw) {
+                const int c = c_lo + cw;
                 const int cg = 16 * j + c;
                 const f32x2* wq = reinterpret_cast<const f32x2*>(dww) + cg * 9;      // host-interleaved (w1, w2) per tap
                 f32x2 acc = reinterpret_cast<const f32x2*>(dwb)[cg] * dbmul;
@@ -179,15 +223,16 @@ __global__ __launch_bounds__(256, 2) void pi_gate_x6_kernel(PgX k, const float* 
                 for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                     for (int dx = 0; dx < 3; ++dx) acc = __builtin_elementwise_fma(wq[3 * dy + dx], tp[dy * PG_HW + dx], acc);
-                hg[c] = acc[0]; hv[c] = acc[1];
+                hg[cw] = acc[0]; hv[cw] = acc[1];
             }
 #pragma unroll
-            for (int c = 0; c < 16; ++c) hg[c] = bem_gelu_fast(hg[c]) * hv[c];
+            for (int cw = 0; cw < NCW; ++cw) hg[cw] = bem_gelu_fast(hg[cw]) * hv[cw];
             if (ost && !(k.dbg & 4)) {
 #pragma unroll
-                for (int c = 0; c < 16; ++c) gb[(int64_t)(16 * j + c) * L] = hg[c];
+                for (int cw = 0; cw < NCW; ++cw) gb[(int64_t)(16 * j + c_lo + cw) * L] = hg[cw];
             }
         }
+        if (WLDS) store_wsh();                                    // phase A of this chunk is behind barrier 1: Wsh is free
         __syncthreads();
     }
 }
@@ -198,8 +243,8 @@ extern "C" int bem_pi_gate_x6_f32(const float* x, const float* ln_w, const float
                                   const float* bias_gate, const float* dw_gate, const float* dwb_gate, float* g, int B, int C, int Hd,
                                   int H, int W, void* stream) {
     BEM_REQUIRE(x && ln_w && ln_b && Wp_gate && dw_gate && g, "pi_gate_x6: null tensor");
-    BEM_REQUIRE(B >= 0 && B <= 65535 && C > 0 && C <= 48 && Hd > 0 && Hd % 16 == 0 && H > 0 && W > 0,
-                "pi_gate_x6: needs C <= 48 and Hd %% 16 == 0 (got C = %d, Hd = %d)", C, Hd);
+    BEM_REQUIRE(B >= 0 && B <= 65535 && C > 0 && C <= 80 && Hd > 0 && Hd % 16 == 0 && H > 0 && W > 0,
+                "pi_gate_x6: needs C <= 80 and Hd %% 16 == 0 (got C = %d, Hd = %d)", C, Hd);
     BEM_REQUIRE(((uintptr_t)Wp_gate & 15) == 0 && (!bias_gate || ((uintptr_t)bias_gate & 15) == 0) && ((uintptr_t)dw_gate & 15) == 0,
                 "pi_gate_x6: packed weights, bias and depthwise weights must be 16-byte aligned");
     BEM_REQUIRE((int64_t)2 * Hd * H * W < (1ll << 31), "pi_gate_x6: plane set too large for 32-bit offsets");
@@ -212,10 +257,13 @@ extern "C" int bem_pi_gate_x6_f32(const float* x, const float* ln_w, const float
     const float bmul = bias_gate ? 1.f : 0.f, dbmul = dwb_gate ? 1.f : 0.f;
     k.C = C; k.Hd = Hd; k.H = H; k.W = W; k.KB = cdiv(C, 16); k.NCH = Hd / 16; k.tx = cdiv(W, PG_TW);
     k.dbg = getenv("BEM_PIG_DBG") ? atoi(getenv("BEM_PIG_DBG")) : 0;
-    dim3 grid(k.tx * cdiv(H, PG_TH), 1, B);
+    const int th = k.KB <= 3 ? 8 : 4;
+    dim3 grid(k.tx * cdiv(H, th), 1, B);
     hipStream_t s = (hipStream_t)stream;
-    if (k.KB <= 1) pi_gate_x6_kernel<1><<<grid, 256, 0, s>>>(k, dw_gate, dwbp, bpi, bmul, dbmul, g);
-    else if (k.KB == 2) pi_gate_x6_kernel<2><<<grid, 256, 0, s>>>(k, dw_gate, dwbp, bpi, bmul, dbmul, g);
-    else pi_gate_x6_kernel<3><<<grid, 256, 0, s>>>(k, dw_gate, dwbp, bpi, bmul, dbmul, g);
+    if (k.KB <= 1) pi_gate_x6_kernel<1, 8, 4><<<grid, 256, 0, s>>>(k, dw_gate, dwbp, bpi, bmul, dbmul, g);
+    else if (k.KB == 2) pi_gate_x6_kernel<2, 8, 4><<<grid, 256, 0, s>>>(k, dw_gate, dwbp, bpi, bmul, dbmul, g);
+    else if (k.KB == 3) pi_gate_x6_kernel<3, 8, 4><<<grid, 256, 0, s>>>(k, dw_gate, dwbp, bpi, bmul, dbmul, g);
+    else if (k.KB == 4) pi_gate_x6_kernel<4, 4, 8><<<grid, 512, 0, s>>>(k, dw_gate, dwbp, bpi, bmul, dbmul, g);
+    else pi_gate_x6_kernel<5, 4, 8><<<grid, 512, 0, s>>>(k, dw_gate, dwbp, bpi, bmul, dbmul, g);
     return bem_check_launch("pi_gate_x6");
 }

@@ -304,11 +304,11 @@ int bem_gate_proj_x6_f32(const float* h, const float* dww, int64_t dww_bstride, 
 
 /* gdMlp front half (vmamba.py:116-131 up to the gate, with the block's norm2 :1330) in one kernel:
  *   g (B,Hd,H,W) = GELU(h[0:Hd]) * h[Hd:2Hd],  h = dw3x3(W_i * LayerNorm2d(x) + b_i) + dwb.
- * x (B,C,H,W) with C <= 48; ln_w / ln_b (C); Wp_gate = bem_pack_pw_weight_x6 of the (2Hd, C) project_in matrix whose rows were
+ * x (B,C,H,W) with C <= 80 (8 x 32 pixel tiles up to C = 48, 4 x 32 beyond); ln_w / ln_b (C); Wp_gate = bem_pack_pw_weight_x6 of the (2Hd, C) project_in matrix whose rows were
  * regrouped per 16 gate channels: packed row 32 j + r = W_i[16 j + r] for r < 16, W_i[Hd + 16 j + r - 16] for r >= 16
  * (Hd % 16 == 0); bias_gate (2Hd, same row order, 16-byte aligned) | NULL; depthwise parameters interleaved per gate channel:
  * dw_gate (Hd,9,2, 16-byte aligned): [c][tap] = (dww[c][tap], dww[Hd + c][tap]); dwb_gate (Hd,2) = (dwb[c], dwb[Hd + c]) | NULL.
- * The 2Hd-channel project_in output only exists as 32-row slices of one 8 x 32 pixel tile in LDS. */
+ * The 2Hd-channel project_in output only exists as 32-row slices of one pixel tile in LDS. */
 int bem_pi_gate_x6_f32(const float* x, const float* ln_w, const float* ln_b, float ln_eps, const float* Wp_gate,
                        const float* bias_gate, const float* dw_gate, const float* dwb_gate, float* g, int B, int C, int Hd,
                        int H, int W, void* stream);
