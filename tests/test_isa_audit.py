@@ -16,7 +16,8 @@ def test_isa_audit_clean():
     assert len(ks) > 150, "kernel discovery broke"
     names = " ".join(k["name"] for k in ks)
     for must in ("ss2d_scan_rows_kernel<1024, 4, 1, 3, 8, true, 1>", "ss2d_scan_bwd_rows_kernel<512, 8, 4, 3>", "wgrad_kernel<1, 2, false, true>",
-                 "pw_x6_stream_kernel<2, 2, false, true, false>", "ln_bwd_split_kernel<10, 4>"):
+                 "pw_x6_stream_kernel<2, 2, false, true, false>", "ln_bwd_split_kernel<10, 4, false, true, true>", "wgrad_x6_kernel<2, 2>",
+                 "pi_gate_x6_kernel<3, 8, 4>", "dwact_bwd_kernel<2, true>"):
         assert must in names, f"default-dispatched kernel {must} not found in the build"
     bad = ia.violations(ks)
     assert not bad, "\n".join(bad)
