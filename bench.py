@@ -172,7 +172,8 @@ def main():
         from basicsr.models import build_model
         from basicsr.utils.options import parse as parse_opt
         opt = parse_opt(os.path.join(PKG, "Options", "DecompDualBranch2DDWavelet_4.yml"), is_train=True)
-        opt["dist"], opt["rank"], opt["world_size"] = world > 1, rank, world
+        # N replicas of the single-GPU config-4 step (BASELINE config 4 / the option file's `dist: false`): no collective inside the step
+        opt["dist"], opt["rank"], opt["world_size"] = False, rank, world
         torch.manual_seed(opt.get("manual_seed", 100))
         model = build_model(opt)
         gt_down = ops.resize_down(gt, opt["condition"]["scale_down"])
