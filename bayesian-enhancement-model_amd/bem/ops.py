@@ -1021,6 +1021,9 @@ def dwact_bwd(t, w, bias, dout, dw, dbias, mode):
 
 
 WGRAD_X6 = os.environ.get("BEM_WGRAD_X6", "1") != "0"      # 1x1 weight gradients on the bf16 matrix cores (no LDS transposes) when L % 32 == 0
+# below this many pixels per launch the x6 form's fixed costs (one wave per SIMD, second reduction launch) lose to the f32-MFMA kernel:
+# Stage-I training (8 x 8 planes) 34.7 -> 23.8 ms per step
+WGRAD_X6_MIN_PIXELS = 16384
 _WGX_WS = {}                                               # per-device scratch of the x6 weight-gradient kernel (stream-ordered reuse)
 
 
@@ -1049,7 +1052,7 @@ def pw_wgrad_(dy, x1, dw, x2=None, dbias=None, blk_rows=0, perm=(0, 1, 2, 3), dy
         a.perm[i] = perm[i]
     a.dbias = dbias.data_ptr() if dbias is not None else 0
     a.B, a.L = B, L
-    if WGRAD_X6 and USE_X6 and L % 32 == 0:
+    if WGRAD_X6 and USE_X6 and L % 32 == 0 and B * L >= WGRAD_X6_MIN_PIXELS:
         n = lib().bem_pw_wgrad_x6_ws_elems(M, C1 + C2, B, L)
         ws = _WGX_WS.get(dw.device)
         if ws is None or ws.numel() < n:

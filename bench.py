@@ -41,7 +41,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", choices=("eval", "train"), default="eval")
+    ap.add_argument("--config", choices=("eval", "train", "train1"), default="eval",
+                    help="eval: the north-star Monte-Carlo loop; train: Stage-II training step (BASELINE config 4); train1: Stage-I (Bayesian) training step")
     ap.add_argument("--images", type=int, default=None, help="images per rank per step (default 8 eval / 16 train)")
     ap.add_argument("--samples", type=int, default=8, help="Bayesian samples per image (eval)")
     ap.add_argument("--size", type=int, default=256)
@@ -120,6 +121,26 @@ def cpu_baseline_train():
             "sample": f"1 training step on one 128x128 pair ({dt:.1f} s CPU), scaled x4 to 256x256"}
 
 
+def cpu_baseline_train1(B, hw):
+    """The oracle's Stage-I training step (KL + EMA prior + L1) on the same batch shape."""
+    import torch
+    from oracle import bem_oracle as O
+    from bem.pipeline import build_nets
+    net1, _ = build_nets(device="cpu")
+    sd = {k: v.detach() for k, v in net1.state_dict().items()}
+    prior = {k.replace("mu_", "prior_mu_").replace("rho_", "prior_rho_"): v.clone() for k, v in sd.items() if "mu_" in k or "rho_" in k}
+    g = torch.Generator().manual_seed(5)
+    lq, gt = torch.rand(B, 3, hw, hw, generator=g) * 0.25, torch.rand(B, 3, hw, hw, generator=g)
+    eps = {(k[:-len("mu_weight")] + "weight" if k.endswith("mu_weight") else k[:-len("mu_bias")] + "bias"): torch.randn(v.shape, generator=g)
+           for k, v in sd.items() if k.endswith(("mu_weight", "mu_bias"))}
+    cores = torch.get_num_threads()
+    t0 = time.perf_counter()
+    O.stage1_train_step_ref(sd, prior, lq, gt, [eps], [None], mini_batch=B)
+    dt = time.perf_counter() - t0
+    return {"value": B / dt, "unit": "img/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "sample": f"1 Stage-I training step, batch {B} at {hw}x{hw} ({dt:.1f} s CPU)"}
+
+
 def psnr_delta_check(dev):
     """Outside the timed region: one small injected-epsilon Monte-Carlo enhancement on the GPU against the CPU oracle -- the
     'PSNR delta vs ref' half of the metric (max over candidates, dB)."""
@@ -164,11 +185,33 @@ def main():
     from bem.pipeline import BEMPipeline, build_nets, synthetic_pair
 
     S, N = args.size, args.samples
-    train = args.config == "train"
-    B = args.images or (16 if train else 8)
+    train = args.config in ("train", "train1")
+    stage1 = args.config == "train1"
+    B = args.images or (8 if stage1 else 16 if train else 8)
+    if stage1 and args.size == 256:
+        S = 128                                      # the option file's gt_size: the net trains on 128 / 16 = 8 x 8 condition planes
     lq, gt = synthetic_pair((B, 3, S, S), seed=287128 + rank, device=dev)     # every rank its own images
 
-    if train:
+    if stage1:
+        from basicsr.models import build_model
+        from basicsr.utils.options import parse as parse_opt
+        opt = parse_opt(os.path.join(PKG, "Options", "CG_UNet_LOLv1.yml"), is_train=True)
+        opt["dist"], opt["rank"], opt["world_size"] = False, rank, world
+        torch.manual_seed(opt.get("manual_seed", 100))
+        model = build_model(opt)
+        sd_ = opt["condition"]["scale_down"]
+        gmask = torch.Generator().manual_seed(3)
+        batch = dict(lq_down=ops.resize_down(lq, sd_), gt=gt, gt_down=ops.resize_down(gt, sd_),
+                     mask=(torch.rand(B, S // sd_, S // sd_, generator=gmask) < 0.4).float().to(dev))
+        it = [0]
+
+        def step(i):
+            it[0] += 1
+            model.update_learning_rate(it[0], warmup_iter=opt["train"].get("warmup_iter", -1))
+            model.feed_train_data(batch)
+            return model.optimize_parameters(it[0])
+        prof_key = args.profile_kernel or "pw_wgrad"
+    elif train:
         from basicsr.models import build_model
         from basicsr.utils.options import parse as parse_opt
         opt = parse_opt(os.path.join(PKG, "Options", "DecompDualBranch2DDWavelet_4.yml"), is_train=True)
@@ -222,7 +265,14 @@ def main():
         out = {"value": imgs / dt, "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic"}
-        if train:
+        if stage1:
+            out["metric"] = f"images/sec (whole node) CG_UNet Stage-I Bayesian training step (fwd+bwd+KL+AdamW) @{S}x{S} crops"
+            out["arithmetic"] = "f32 storage and accumulation; 1x1 GEMM products as exact 3-limb bf16 expansions"
+            out["config"] = {"workload": f"CG_UNet_LOLv1.yml training step (EMA prior + sampled weights + MIM mask, KL + L1, clip, AdamW), batch={B}, "
+                                         f"{S}x{S} crops -> {S // 16}x{S // 16} condition planes per GPU", "images_per_gpu": B,
+                             "parallelism": f"replicas x{world}", "note": "launch-bound: ~2000 launches on 8x8 .. 2x2 planes"}
+            bytes_img = 3.0 * BYTES_STAGE1_PER_SAMPLE * (S * S / 65536.0)
+        elif train:
             out["metric"] = f"images/sec (whole node) DecompDualBranchDDWavelet Stage-II training step (fwd+bwd+AdamW) @{S}x{S}"
             out["arithmetic"] = "f32 storage and accumulation; forward, input-gradient and weight-gradient 1x1 GEMMs as exact 3-limb bf16 expansions (6 MFMA products), conv weight gradients on f32 MFMA"
             out["config"] = {"workload": f"DecompDualBranch2DDWavelet_4.yml training step (fwd+bwd+clip+AdamW), batch={B} {S}x{S} per GPU, L1 loss",
@@ -255,7 +305,7 @@ def main():
             out["roofline"] = rl
         out["path_hbm_roofline_frac"] = (out["value"] / world) * bytes_img / (HBM_PEAK_GBS * 1e9)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_train() if train else cpu_baseline_eval(N)
+            out["cpu_baseline"] = cpu_baseline_train1(B, S // 16) if stage1 else cpu_baseline_train() if train else cpu_baseline_eval(N)
             out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
             if not train:
                 out["psnr_delta_db"] = psnr_delta_check(dev)

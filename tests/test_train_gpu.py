@@ -142,9 +142,14 @@ def test_dwact_bwd(dev, shape, mode, bias):
 @pytest.mark.parametrize("B,M,C1,C2,L", [(2, 40, 40, 0, 192), (1, 320, 40, 0, 1024), (2, 20, 40, 0, 77), (3, 80, 80, 80, 130), (1, 640, 160, 0, 64),
                                          (2, 33, 7, 0, 31), (1, 160, 320, 0, 100), (2, 16, 64, 0, 256), (3, 80, 80, 80, 144), (4, 320, 40, 0, 4096),
                                          (2, 40, 160, 0, 1024), (5, 7, 33, 0, 16)])
-def test_pw_wgrad(dev, B, M, C1, C2, L):
-    """L % 16 == 0 runs bem_pw_wgrad_x6_f32 (operands straight into the bf16 matrix cores), other sizes bem_pw_wgrad_f32."""
+@pytest.mark.parametrize("form", ["x6", "f32"])
+def test_pw_wgrad(dev, B, M, C1, C2, L, form, monkeypatch):
+    """Both weight-gradient forms on every shape: bem_pw_wgrad_x6_f32 (L % 32 == 0; operands straight into the bf16 matrix cores, normally
+    chosen for launches of >= 16384 pixels) and bem_pw_wgrad_f32."""
     from bem import ops
+    if form == "x6" and L % 32:
+        pytest.skip("the x6 form needs L % 32 == 0")
+    monkeypatch.setattr(ops, "WGRAD_X6_MIN_PIXELS", 0 if form == "x6" else 1 << 62)
     g = G(5)
     dy = torch.randn(B, M, L, generator=g)
     x1 = torch.randn(B, C1, L, generator=g)
@@ -159,9 +164,11 @@ def test_pw_wgrad(dev, B, M, C1, C2, L):
     close(db, dy.double().sum(dim=(0, 2)), 0.0, 1e-5 * float(dy.abs().sum(dim=(0, 2)).max()), "dbias")
 
 
-def test_pw_wgrad_row_blocks_and_strided_dy(dev):
+@pytest.mark.parametrize("form", ["x6", "f32"])
+def test_pw_wgrad_row_blocks_and_strided_dy(dev, form, monkeypatch):
     """The stacked x_proj form: dy is a channel slice of a wider tensor and the row blocks of dw are permuted ([0,2,1,3])."""
     from bem import ops
+    monkeypatch.setattr(ops, "WGRAD_X6_MIN_PIXELS", 0 if form == "x6" else 1 << 62)
     g = G(6)
     B, R2, C, L = 2, 5, 40, 192
     wide = torch.randn(B, 4 * R2 + 3, L, generator=g)
