@@ -1023,7 +1023,7 @@ def dwact_bwd(t, w, bias, dout, dw, dbias, mode):
 WGRAD_X6 = os.environ.get("BEM_WGRAD_X6", "1") != "0"      # 1x1 weight gradients on the bf16 matrix cores (no LDS transposes) when L % 32 == 0
 # below this many pixels per launch the x6 form's fixed costs (one wave per SIMD, second reduction launch) lose to the f32-MFMA kernel:
 # Stage-I training (8 x 8 planes) 34.7 -> 23.8 ms per step
-WGRAD_X6_MIN_PIXELS = 16384
+WGRAD_X6_MIN_PIXELS = int(os.environ.get("BEM_WGRAD_X6_MIN_PIXELS", "16384"))
 _WGX_WS = {}                                               # per-device scratch of the x6 weight-gradient kernel (stream-ordered reuse)
 
 
