@@ -11,7 +11,7 @@ wd = d(torch.randn(2 * Hd, 1, 3, 3, generator=g) / 3); bd = d(torch.randn(2 * Hd
 perm = ops.gate_order(Hd, "cuda")
 Wg = ops.pack_pw_weight(wi[perm].contiguous(), x6=True); bg = bi[perm].contiguous()
 wdg, bdg = ops.dw_gate_params(wd, bd, Hd)
-for dbg in [0, 1, 2, 0]:
+for dbg in [0]:
     os.environ["BEM_PIG_DBG"] = str(dbg)
     for _ in range(3): ops.pi_gate(x, lw, lb, 1e-6, Wg, bg, wdg, bdg, Hd)
     torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
