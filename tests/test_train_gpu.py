@@ -273,11 +273,17 @@ def test_vssblock_backward_golden(dev):
         close(params[k].grad, ref, 2e-3, 1e-5 * float(ref.abs().max()) + 1e-7, k)
 
 
-def test_vssblock_backward_all_grads_vs_oracle(dev):
+@pytest.mark.parametrize("wgrad_form", ["default", "x6"])
+def test_vssblock_backward_all_grads_vs_oracle(dev, wgrad_form, monkeypatch):
     """Every parameter gradient of the block against autograd through the oracle (pinned to the reference by the test above
-    and by tests/test_oracle_golden.py), on a plane with odd sizes (general kernels) and on 32x32 (row-major scan form)."""
+    and by tests/test_oracle_golden.py), on a plane with odd sizes (general kernels) and on 32x32 (row-major scan form).  'x6' forces
+    the bf16-matrix-core weight-gradient kernel wherever L % 32 == 0 (by default it takes launches of >= 16384 pixels only): all its
+    call forms inside the block -- LayerNorm-ed input, strided dy with permuted row blocks (x_proj), bias sums."""
+    from bem import ops
     from bem.modules import VSSBlock
     from oracle import bem_oracle as O
+    if wgrad_form == "x6":
+        monkeypatch.setattr(ops, "WGRAD_X6_MIN_PIXELS", 0)
     sd0 = load_golden("g4_vssblock")["sd"]
     for (H, W), seed in (((9, 7), 11), ((32, 32), 12)):
         g = G(seed)
