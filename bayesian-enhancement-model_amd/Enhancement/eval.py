@@ -89,8 +89,8 @@ def main(argv=None):
     load_params(net, args.weights)
     load_params(cond_net, args.cond_weights)
     net, cond_net = net.cuda().eval(), cond_net.cuda().eval()
-    cnd = opt.get("condition", {})
-    pipe = BEMPipeline(net, cond_net, cnd.get("scale_down", 16), cnd.get("noise_level", 0.1))
+    # scale from the Stage-I option file, noise level from the Stage-II one, default 0 (eval.py:174-176,207)
+    pipe = BEMPipeline(net, cond_net, opt.get("condition", {}).get("scale_down", 16), cond_opt.get("condition", {}).get("noise_level", 0))
     result_dir = os.path.join(args.result_dir, args.dataset)
     os.makedirs(result_dir, exist_ok=True)
     names = sorted(f for f in os.listdir(args.input_dir) if f.lower().endswith((".png", ".jpg", ".jpeg", ".bmp")))

@@ -40,6 +40,15 @@ class BaseModel:
     def model_to_device(self, net):
         return net.to(self.device)
 
+    def sync_gradients(self, optimizer):
+        """opt['dist']: average the gradients over the ranks before clipping (what the reference gets from DistributedDataParallel,
+        base_model.py:97-100); without an initialised process group a distributed option file is an error, not N silent replicas."""
+        if not self.opt.get("dist"):
+            return
+        if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            raise RuntimeError("opt['dist'] is set but torch.distributed is not initialised (launch with --launcher pytorch)")
+        optimizer.all_reduce_grads()
+
     def get_bare_model(self, net):
         return net.module if hasattr(net, "module") else net
 
@@ -54,6 +63,8 @@ class BaseModel:
 
     def save_network(self, net, net_label, current_iter, param_key="params"):
         """``<models>/<net_label>_<iter>.pth`` (iter -1 -> 'latest'); net / param_key may be lists of equal length (base_model.py:236-280)."""
+        if self.opt.get("rank", 0) != 0:                       # @master_only in the reference (base_model.py:235)
+            return None
         it = "latest" if current_iter == -1 else current_iter
         save_path = os.path.join(self.opt["path"]["models"], f"{net_label}_{it}.pth")
         nets = net if isinstance(net, list) else [net]

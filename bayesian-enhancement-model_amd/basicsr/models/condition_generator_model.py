@@ -95,12 +95,54 @@ class ConditionGenerator(BaseModel):
         loss_dict["l_pix"] = l_pix.detach() if w == 1 else l_pix.detach() / w
         l_total = ag.ScaledSumFn.apply(l_pix, l_kl, 0.01 / self.opt["datasets"]["train"]["mini_batch_sizes"][0])
         l_total.backward()
+        self.sync_gradients(self.optimizer_g)
         mgn = self.opt["train"].get("max_grad_norm")
         total_norm = self.optimizer_g.clip_grad_norm_(mgn if mgn else float("inf"))
         # a parameter outside this iteration's graph has .grad None in the reference and is skipped by AdamW: the mask token without a mask
         self.optimizer_g.step(skip=[self.net_g.mask_token] if self.mask is None else ())
         self.log_dict = self.reduce_loss_dict(loss_dict)
         return total_norm
+
+    # -- validation (:236-334) ----------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def validation(self, dataloader, current_iter, tb_logger=None, save_img=False, rgb2bgr=True, use_image=True):
+        """Mean PSNR of the predicted condition planes against the down-sampled ground truth, deterministic weights (mu), float form on
+        the device."""
+        from basicsr.bayesian import set_prediction_type
+        from bem import ops
+        was_training = self.net_g.training
+        self.net_g.eval()
+        set_prediction_type(self.net_g, True)
+        tot, cnt = 0.0, 0
+        for data in dataloader:
+            self.feed_data(data)
+            pred = self.net_g(self.lq.contiguous())[-1]
+            h, w = pred.shape[-2:]
+            _, ps = ops.candidate_finalize(pred.contiguous(), self.gt.contiguous(), 1, h, w, False)
+            tot += float(ps.sum())
+            cnt += pred.shape[0]
+        set_prediction_type(self.net_g, False)
+        if was_training:
+            self.net_g.train()
+        self.metric_results = {"psnr": tot / max(cnt, 1)}
+        if self.opt.get("rank", 0) == 0:
+            print(f"Validation,\t\t # psnr: {self.metric_results['psnr']:.4f}", flush=True)
+        return self.metric_results["psnr"]
+
+    def save_best(self, best_metric, param_key="params"):
+        import glob
+        import os
+        if self.opt.get("rank", 0) != 0:
+            return None
+        root = self.opt["path"]["experiments_root"]
+        path = os.path.join(root, f"best_psnr_{best_metric['psnr']:.2f}_{best_metric['iter']}.pth")
+        if not os.path.exists(path):
+            for f in glob.glob(f"{root}/best_*"):
+                os.remove(f)
+            sd = {(k[7:] if k.startswith("module.") else k): v.detach().cpu() for k, v in self.get_bare_model(self.net_g).state_dict().items()}
+            os.makedirs(root, exist_ok=True)
+            torch.save({param_key: sd}, path)
+        return path
 
     # -- checkpoints (:346-370) ---------------------------------------------------------------------------------------------
     def save(self, epoch, current_iter, **kwargs):

@@ -74,9 +74,13 @@ class ImageEnhancer(BaseModel):
             raise NotImplementedError("condition type 'histogram' is not used by the shipped option files")
         gd = data["gt_down"].to(dev).contiguous()
         nl = cond.get("noise_level", 0)
-        # conds = gt_down + randn_like(gt_down) * noise_level  (:143-148); the draw comes from the device Philox stream
-        self._cond_calls = getattr(self, "_cond_calls", 0) + 1
-        self.conds = ops.add(gd, ops.randn(tuple(gd.shape), dev, int(self.opt.get("manual_seed", 0) or 0), (1 << 41) + self._cond_calls), nl) if nl else gd
+        # conds = gt_down + randn_like(gt_down) * noise_level  (:143-148); the draw comes from the device Philox stream in the reserved
+        # condition-noise key space (bit 62, as BEMPipeline.candidates): unique per rank and per iteration, so replicas never share a draw
+        # and a resumed run continues the sequence instead of replaying it
+        it = int(getattr(self, "current_iter_hint", 0)) or (getattr(self, "_cond_calls", 0) + 1)
+        self._cond_calls = it
+        key = (1 << 62) | (int(self.opt.get("rank", 0)) << 44) | (it & ((1 << 44) - 1))
+        self.conds = ops.add(gd, ops.randn(tuple(gd.shape), dev, int(self.opt.get("manual_seed", 0) or 0), key), nl) if nl else gd
 
     feed_data = feed_train_data
 
@@ -95,11 +99,42 @@ class ImageEnhancer(BaseModel):
         w = self.opt["train"]["pixel_opt"].get("loss_weight", 1)
         loss_dict["l_pix"] = l_pix.detach() if w == 1 else l_pix.detach() / w
         l_total.backward()
+        self.sync_gradients(self.optimizer_g)
         mgn = self.opt["train"].get("max_grad_norm")
         total_norm = self.optimizer_g.clip_grad_norm_(mgn if mgn else float("inf"))
         self.optimizer_g.step()
         self.log_dict = self.reduce_loss_dict(loss_dict)
         return total_norm
+
+    # -- validation (image_enhancer_model.py:259-325) -------------------------------------------------------------------------
+    @torch.no_grad()
+    def validation(self, dataloader, current_iter, tb_logger=None, save_img=False, rgb2bgr=True, use_image=True):
+        """Mean PSNR of net_g over a validation loader, conditions derived from the ground truth as in training (feed_data: gt_down +
+        noise).  The inference kernels run the forward; PSNR is the float form ``10 log10(1 / mse)`` on [0,1] tensors computed on the
+        device (the reference's ``use_image: false`` branch; its uint8 / cv2 image branch and image dumps are host-side reporting)."""
+        from bem import ops
+        was_training = self.net_g.training
+        self.net_g.eval()
+        s = self.opt["condition"].get("scale_down", 0) + self.opt["condition"].get("hist_patch_size", 0)
+        tot, cnt = 0.0, 0
+        for data in dataloader:
+            self.feed_train_data(data)
+            B, _, H, W = self.lq.shape
+            x = torch.empty(B, 6, H, W, device=self.lq.device, dtype=torch.float32)
+            ops.copy_channels(self.lq.contiguous(), x, 0)
+            ops.bilinear_up(self.conds, s, dst=x, dst_c0=3)
+            pred = self.net_g(x)[-1]
+            h, w = data.get("crop_hw", (H, W))
+            gt = self.gt[..., :h, :w].contiguous()
+            _, ps = ops.candidate_finalize(pred.contiguous(), gt, 1, h, w, False)
+            tot += float(ps.sum())
+            cnt += B
+        if was_training:
+            self.net_g.train()
+        self.metric_results = {"psnr": tot / max(cnt, 1)}
+        if self.opt.get("rank", 0) == 0:
+            print(f"Validation {getattr(dataloader.dataset, 'opt', {}).get('name', 'val')},\t\t # psnr: {self.metric_results['psnr']:.4f}", flush=True)
+        return self.metric_results["psnr"]
 
     # -- checkpoints (image_enhancer_model.py:340-370) --------------------------------------------------------------------
     def save(self, epoch, current_iter, **kwargs):
@@ -110,6 +145,8 @@ class ImageEnhancer(BaseModel):
         """``<experiments_root>/best_psnr_<psnr>_<iter>.pth``, replacing any earlier best_* file."""
         import glob
         import os
+        if self.opt.get("rank", 0) != 0:
+            return None
         root = self.opt["path"]["experiments_root"]
         path = os.path.join(root, f"best_psnr_{best_metric['psnr']:.2f}_{best_metric['iter']}.pth")
         if not os.path.exists(path):

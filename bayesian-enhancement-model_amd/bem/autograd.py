@@ -20,6 +20,7 @@ import torch
 from torch.autograd import Function
 
 from . import ops
+from .native import BemNativeError
 from .native import check, lib
 
 WEIGHT_EPOCH = ops.WEIGHT_EPOCH      # see bem.ops: bumped by optimizer steps that rewrite parameters in place
@@ -222,6 +223,8 @@ def _wT4(w):
 class Conv2dFn(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, holder, cin_slice):
+        if holder.dilation[0] != 1:
+            raise BemNativeError("Conv2dFn: the training path covers undilated convolutions only (the dilated QD model2 layers are frozen)")
         x = x.contiguous()
         ctx.save_for_backward(x)
         ctx.holder, ctx.weight, ctx.bias, ctx.cin_slice = holder, weight, bias, cin_slice

@@ -9,6 +9,11 @@ Two forms of the exchange (BASELINE north star asks for the first; SURVEY 5 / 8e
   scores     : ranks select locally (image-major sharding keeps an image's N candidates on one rank), gather the winners and
                the score table only (N x less payload).
 Both return identical (best index, best image) for every image -- tests/test_dist_cpu.py.
+
+Sample-major sharding (``shard_samples`` / ``gather_samples`` / ``enhance_sample_sharded``) is the split for B < world -- the way the
+eval driver is actually called (Enhancement/eval.py:160-222 feeds ONE image at a time): the N samples of every image are block-partitioned
+over the ranks, each rank recomputes decomp(image) for its samples, and the same all-gather brings the candidates back into the
+unsharded (image, sample) order, so the first-maximum selection sees exactly the list the single-GPU run sees.
 The reference has no collective on this path: nothing to mirror, only results to match."""
 from __future__ import annotations
 
@@ -142,3 +147,65 @@ def enhance_sharded(enhance: Callable, imgs: torch.Tensor, targets: Optional[tor
         score = imgs.new_zeros((0,))
     ragged = len(set(counts)) > 1
     return exchange_and_select(final, score, N, world, mode, counts if ragged else None)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# sample-major sharding: the N samples of each image are split over the ranks (B < world, e.g. the eval driver's B = 1)
+# ------------------------------------------------------------------------------------------------------------------
+def shard_samples(num_samples: int, rank: int, world: int):
+    """Block partition of the sample indices 0..N-1: (start, stop) of this rank.  Blocks are ordered by rank, so "first maximum over
+    the gathered list" is the first maximum of the unsharded sample order."""
+    return shard_images(num_samples, rank, world)
+
+
+def gather_samples(t: torch.Tensor, n_images: int, num_samples: int, rank: int, world: int) -> torch.Tensor:
+    """t (B * n_local, ...) with rows = image * n_local + local sample (this rank's block of samples of EVERY image)
+    -> (B * N, ...) with rows = image * N + sample on every rank.  One all-gather of the (padded) blocks, then an index permutation."""
+    if world == 1:
+        return t
+    counts = [shard_samples(num_samples, r, world)[1] - shard_samples(num_samples, r, world)[0] for r in range(world)]
+    m, n_loc = max(counts), counts[rank]
+    B = n_images
+    blk = t.reshape((B, n_loc) + tuple(t.shape[1:]))
+    if n_loc < m:
+        blk = torch.cat([blk, blk.new_zeros((B, m - n_loc) + tuple(t.shape[1:]))], 1)
+    g = _all_gather_rows(blk.reshape((B * m,) + tuple(t.shape[1:])), world)                 # rows = (rank, image, slot)
+    idx = [(r * B + b) * m + sl for b in range(B) for r in range(world) for sl in range(counts[r])]
+    return g.index_select(0, torch.tensor(idx, device=g.device))
+
+
+def enhance_sample_sharded(candidates: Callable, imgs: torch.Tensor, targets: Optional[torch.Tensor], num_samples: int, rank: int, world: int,
+                           mode: str = "candidates", **kw):
+    """The multi-GPU eval step for FEW images (B < world): every rank draws its block of the N samples of every image.
+    ``candidates(imgs, targets, n_local, sample_offset=lo, total_samples=N, **kw)`` has BEMPipeline.candidates' contract and returns
+    dict(final (B*n_local,3,h,w), psnr (B*n_local)).  Returns (best images (B,3,h,w), best index (B)), identical on every rank and
+    identical to the unsharded selection (first maximum, eval.py:284-285).
+    mode 'candidates': all-gather of every candidate + score; 'scores': all-gather of the score table only, the winners are
+    contributed by their owners through one all-reduce of (B,3,h,w) (every other rank adds exact zeros)."""
+    N, B = num_samples, imgs.shape[0]
+    lo, hi = shard_samples(N, rank, world)
+    if hi > lo:
+        r = candidates(imgs, targets, hi - lo, sample_offset=lo, total_samples=N, **kw)
+        final, score = r["final"], r["psnr"]
+    else:                                                 # more ranks than samples: an empty block still joins the collectives
+        h, w = kw.get("hw_hint", tuple(imgs.shape[2:]))
+        final, score = imgs.new_zeros((0, 3, h, w)), imgs.new_zeros((0,))
+    if world == 1:
+        best, img = _select_device(final, score, N)
+        return img, best
+    gs = gather_samples(score, B, N, rank, world)
+    if mode == "candidates":
+        best, img = _select_device(gather_samples(final, B, N, rank, world), gs, N)
+        return img, best
+    if mode != "scores":
+        raise ValueError(f"enhance_sample_sharded: unknown mode {mode}")
+    best, _ = _select_device(gs.new_zeros((B * N, 1)), gs, N)             # selection needs the scores only
+    mine = (best >= lo) & (best < hi)
+    loc = (best - lo).clamp(0, max(hi - lo - 1, 0))
+    if hi > lo:
+        pick = final.reshape((B, hi - lo) + tuple(final.shape[1:]))[torch.arange(B, device=final.device), loc]
+        img = pick * mine.view(B, 1, 1, 1).to(pick.dtype)
+    else:
+        img = final.new_zeros((B,) + tuple(final.shape[1:]))
+    dist.all_reduce(img)
+    return img, best

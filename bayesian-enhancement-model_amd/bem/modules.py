@@ -423,6 +423,20 @@ class gdMlp(nn.Module):
         if FUSE_GDMLP and ops.gdmlp_fused_supported(C, Hd) and _has_bias(self.project_in):
             Wpi, bpi, dww, dwb, Wpo, bpo = self._fused_params(B)
             return ops.gdmlp_fused(x, norm.weight.detach(), norm.bias.detach(), norm.eps, Wpi, bpi, dww, dwb, Wpo, bpo, Hd)
+        if isinstance(self.project_in, PwConv2d) and isinstance(self.dwconv, DwConv2d) and isinstance(self.project_out, PwConv2d) \
+                and ops.gdmlp_x6_supported(C, Hd):
+            # the whole branch in one kernel (bem_gdmlp_x6_f32): neither the 2Hd-channel nor the Hd-channel tensor reaches HBM
+            pi, dw, po = self.project_in, self.dwconv, self.project_out
+
+            def prep():
+                perm = ops.gate_interleave(Hd, pi.weight.device)
+                bg = pi.bias.detach()[perm].contiguous() if pi.bias is not None else torch.zeros(2 * Hd, device=pi.weight.device)
+                return (ops.pack_pw_weight(pi.weight.detach().reshape(2 * Hd, C)[perm].contiguous(), x6=True), bg) + \
+                    ops.dw_gate_params(dw.weight.detach(), None if dw.bias is None else dw.bias.detach(), Hd) + \
+                    (ops.pack_pw_weight(po.weight.detach().reshape(po.out_channels, Hd).contiguous(), x6=True),
+                     None if po.bias is None else po.bias.detach().contiguous())
+            Wg, bg, w, bw, Wo, bo = self._cache.get("gdmlp_x6", [t for t in (pi.weight, pi.bias, dw.weight, dw.bias, po.weight, po.bias) if t is not None], prep)
+            return ops.gdmlp_x6(x, norm.weight.detach(), norm.bias.detach(), norm.eps, Wg, bg, w, bw, Wo, bo, Hd)
         if PI_GATE and isinstance(self.project_in, PwConv2d) and isinstance(self.dwconv, DwConv2d) and ops.pi_gate_supported(C, Hd):
             # the 2Hd-channel project_in output lives only in LDS (bem_pi_gate_x6_f32); deterministic weights, C <= ops.PI_GATE_MAXC
             pi, dw = self.project_in, self.dwconv

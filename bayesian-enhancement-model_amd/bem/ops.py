@@ -353,6 +353,49 @@ def pi_gate(x, ln_w, ln_b, ln_eps, Wp_gate, bias_gate, dww, dwb, Hd):
     return g
 
 
+def gate_interleave(Hd, device):
+    """row permutation of a (2Hd, ...) project_in parameter into the gate-interleaved order of bem_gdmlp_x6_f32:
+    new row 32 j + 2 c + s = old row s Hd + 16 j + c."""
+    j = torch.arange(Hd // 16, device=device)[:, None, None]
+    c = torch.arange(16, device=device)[None, :, None]
+    s_ = torch.arange(2, device=device)[None, None, :]
+    return (s_ * Hd + 16 * j + c).reshape(-1)
+
+
+# the fully fused gdMlp branch (bem_gdmlp_x6_f32): C <= GDMLP_X6_MAXC, deterministic weights.  BEM_GDMLP_X6=0 restores the chains.
+GDMLP_X6 = os.environ.get("BEM_GDMLP_X6", "1") != "0"
+GDMLP_X6_MAXC = int(os.environ.get("BEM_GDMLP_X6_MAXC", "80"))
+
+
+def gdmlp_x6_supported(C, Hd):
+    return USE_X6 and GDMLP_X6 and C <= GDMLP_X6_MAXC and Hd % 16 == 0
+
+
+def gdmlp_x6(x, ln_w, ln_b, ln_eps, Wp_gate, bias_gate, dww, dwb, Wp_out, bias_out, Hd):
+    """x + project_out(GELU(h1) * h2) + b_o with [h1; h2] = dw3x3(project_in(LayerNorm2d(x))) in ONE kernel (bem_gdmlp_x6_f32).
+    Wp_gate = pack_pw_weight(W_i[gate_interleave(Hd)], x6=True), bias_gate = b_i[gate_interleave(Hd)] (zeros without a bias);
+    dww, dwb = dw_gate_params(...); Wp_out = pack_pw_weight(W_o, x6=True)."""
+    for n_, t in (("x", x), ("ln_w", ln_w), ("ln_b", ln_b), ("Wp_gate", Wp_gate), ("bias_gate", bias_gate), ("dww", dww), ("Wp_out", Wp_out)):
+        _chk(t, n_)
+    _chk(dwb, "dwb", optional=True); _chk(bias_out, "bias_out", optional=True)
+    B, C, H, W = x.shape
+    if not (USE_X6 and C <= 80 and Hd % 16 == 0):
+        raise ValueError(f"gdmlp_x6: C = {C} (<= 80) / Hd = {Hd} (% 16) not supported")
+    if tuple(dww.shape) != (Hd, 9, 2) or (dwb is not None and tuple(dwb.shape) != (Hd, 2)):
+        raise ValueError("gdmlp_x6: depthwise parameters must come from dw_gate_params")
+    if ln_w.numel() != C or ln_b.numel() != C or bias_gate.numel() != 2 * Hd or (bias_out is not None and bias_out.numel() != C):
+        raise ValueError("gdmlp_x6: parameter shapes")
+    for Wp, (M, K), nm in ((Wp_gate, (2 * Hd, C), "Wp_gate"), (Wp_out, (C, Hd), "Wp_out")):
+        if Wp.dim() != 2 or Wp.shape[0] != 1 or Wp.shape[1] != packed_elems(M, K, True) or getattr(Wp, "_bem_mk", (M, K)) != (M, K):
+            raise ValueError(f"gdmlp_x6: {nm} {tuple(Wp.shape)} does not match M={M} K={K} (x6 format, one weight set)")
+    out = torch.empty_like(x)
+    s = _timed("gdmlp_x6", 8.0 * x.numel(), 2.0 * B * H * W * (2 * Hd * C + Hd * C + 2 * Hd * 9)) if _PROF is not None else None
+    check(lib().bem_gdmlp_x6_f32(_p(x), _p(ln_w), _p(ln_b), float(ln_eps), _p(Wp_gate), _p(bias_gate), _p(dww), _p(dwb), _p(Wp_out),
+                                 _p(bias_out), _p(out), B, C, Hd, H, W, _stream()), "gdmlp_x6")
+    _timed_end(s)
+    return out
+
+
 def pack_pw_weight_gate(W, Hd):
     """project_in weight (2Hd,K) or (nsets,2Hd,K) -> packed with gate rows regrouped per 16 channels."""
     _chk(W, "W")
@@ -1149,6 +1192,8 @@ _KEYS = {
     "pw_gemm3_reg<20,2>": ("pw_gemm", "hbm", "pw_gemm3_reg_kernel<20, 2, true, false>", lambda K, M, ln, L, mode: K <= 40 and M > 32 and L % 4 == 0 and mode != 1),
     "pw_gemm": ("pw_gemm", "mfma", "pw_gemm* (all variants)", lambda K, M, ln, L, mode: True),
     "gdmlp_fused": ("gdmlp_fused", "mfma", "gdmlp_fused_kernel", None),
+    # the whole gdMlp branch in one kernel: x in, out out -- 8 bytes per element of x are its algorithmic bytes
+    "gdmlp_x6": ("gdmlp_x6", "hbm", "gdmlp_x6_kernel<3, 2, 3>", None),
     "conv2d": ("conv2d", "mfma", "conv2d_kernel", None),
     "dwconv3x3": ("dwconv3x3", "hbm", "dwconv3x3_kernel", None),
     "ss2d_scan": ("ss2d_scan", "hbm", "ss2d_scan_kernel", None),

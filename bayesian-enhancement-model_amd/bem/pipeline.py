@@ -27,12 +27,22 @@ class BEMPipeline:
     @torch.no_grad()
     def candidates(self, imgs, targets, num_samples: int, gt_mean: bool, deterministic: bool = False,
                    eps: Optional[Dict[str, torch.Tensor]] = None, noise: Optional[torch.Tensor] = None,
-                   img_down: Optional[torch.Tensor] = None, seed: int = 0, rank: int = 0):
+                   img_down: Optional[torch.Tensor] = None, seed: int = 0, rank: int = 0, sample_offset: int = 0,
+                   total_samples: Optional[int] = None):
         """imgs (B,3,h,w) in [0,1] on the GPU, targets (B,3,h,w) or None.
-        Returns dict(conds (B*N,3,hd,wd), raw (B*N,3,Hp,Wp), final (B*N,3,h,w), psnr (B*N)); row = image*N + sample."""
+        Returns dict(conds (B*N,3,hd,wd), raw (B*N,3,Hp,Wp), final (B*N,3,h,w), psnr (B*N)); row = image*N + sample.
+        ``sample_offset`` / ``total_samples``: this call draws samples [offset, offset + num_samples) of ``total_samples`` per image
+        (sample-major multi-GPU sharding, bem.dist): injected ``eps`` / ``noise`` are given for ALL (image, sample) rows and sliced here."""
         from basicsr.bayesian import set_prediction_type
         B, _, h, w = imgs.shape
         N = 1 if deterministic else num_samples
+        NT = total_samples or N
+        if not deterministic and (eps is not None or noise is not None) and NT != N:
+            rows = (torch.arange(B)[:, None] * NT + sample_offset + torch.arange(N)[None, :]).reshape(-1).to(imgs.device)
+            if eps is not None:
+                eps = {k_: v.index_select(0, rows) for k_, v in eps.items()}
+            if noise is not None:
+                noise = noise.index_select(0, rows)
         f = 4 * self.scale
         Hp = (((h + f) // f) * f) if h % f else h                                # _padimg_np, eval.py:146-153
         Wp = (((w + f) // f) * f) if w % f else w
@@ -67,12 +77,28 @@ class BEMPipeline:
         return rel.index(max(rel))
 
     @torch.no_grad()
-    def enhance(self, imgs, targets, num_samples, gt_mean=True, deterministic=False, sync=True, scorer=None, monte_carlo=False, **kw):
+    def enhance(self, imgs, targets, num_samples, gt_mean=True, deterministic=False, sync=True, scorer=None, monte_carlo=False, shard=None, **kw):
         """candidates + per-image selection.  Default selection = the full-reference PSNR rule (first maximum of psnr / max(psnr),
         eval.py:284-285) on the device; ``scorer`` (bem.scorers) switches to the PSNR/SSIM-weighted rule or a no-reference
         scorer (eval.py:268-281).  ``monte_carlo``: also returns the Monte-Carlo mean prediction (eval.py:224-225,308-314) with its
         PSNR / SSIM.  With ``sync=False`` nothing is copied to the host."""
-        r = self.candidates(imgs, targets, num_samples, gt_mean, deterministic, **kw)
+        if shard is not None and shard[1] > 1 and not deterministic:
+            # sample-major multi-GPU form (bem.dist): this rank draws its block of the N samples of every image, one RCCL all-gather per
+            # tensor brings candidates, scores (and raw outputs for the Monte-Carlo mean) back into the unsharded (image, sample) order
+            from . import dist as bdist
+            rank, world = shard
+            kw.pop("rank", None)
+            lo, hi = bdist.shard_samples(num_samples, rank, world)
+            B = imgs.shape[0]
+            r = self.candidates(imgs, targets, max(hi - lo, 1), gt_mean, False, rank=rank, sample_offset=lo, total_samples=num_samples, **kw)
+            for k_ in ("final", "psnr", "conds") + (("raw",) if monte_carlo else ()):
+                t = r[k_] if hi > lo else r[k_][:0]
+                r[k_] = bdist.gather_samples(t.contiguous(), B, num_samples, rank, world)
+            if not monte_carlo:
+                r.pop("raw")
+            r["N"] = num_samples
+        else:
+            r = self.candidates(imgs, targets, num_samples, gt_mean, deterministic, **kw)
         N = r["N"]
         h, w = imgs.shape[-2:]
         if scorer is not None:

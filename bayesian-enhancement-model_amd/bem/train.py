@@ -28,6 +28,7 @@ class BemAdamW(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self._flat = []          # per group: dict(p, g, m, v, n, params)
         self._steps = 0
+        self._lag = {}           # parameter -> steps it is behind the shared counter (skipped iterations)
         self._max_norm = 0.0
         self._sumsq = None
         self._norm = None
@@ -71,6 +72,22 @@ class BemAdamW(torch.optim.Optimizer):
                     p.grad = f["g"][off:off + n].view(p.shape)
                 off += _align4(n)
 
+    def all_reduce_grads(self):
+        """Data-parallel training: average the flat gradient buffers over the ranks (one RCCL all-reduce per parameter group -- the
+        whole-model bucket that DistributedDataParallel converges to; reference wrap: basicsr/models/base_model.py:97-100)."""
+        import torch.distributed as dist
+        world = dist.get_world_size()
+        if world == 1:
+            return
+        for f in self._flat:
+            if f is None:
+                continue
+            if dist.get_backend() == "nccl":
+                dist.all_reduce(f["g"], op=dist.ReduceOp.AVG)
+            else:                                                   # gloo (tests): no AVG
+                dist.all_reduce(f["g"])
+                f["g"].mul_(1.0 / world)
+
     def clip_grad_norm_(self, max_norm: float):
         """torch.nn.utils.clip_grad_norm_ over every group's gradients (L2, error_if_nonfinite=False).  The scaling happens inside
         the next step(); returns a 1-element device tensor that holds the total norm once that step has run."""
@@ -81,13 +98,30 @@ class BemAdamW(torch.optim.Optimizer):
         self._max_norm = float(max_norm)
         return self._norm
 
+    def _slices(self, p):
+        """(flat parameter, gradient, first moment, second moment) views of one parameter, and its group's hyper-parameters."""
+        for group, f in zip(self.param_groups, self._flat):
+            if f is None:
+                continue
+            off = 0
+            for q in f["params"]:
+                n = q.numel()
+                if q is p:
+                    return tuple(f[k][off:off + n] for k in ("p", "g", "m", "v")), group
+                off += _align4(n)
+        raise KeyError("BemAdamW: parameter is not in any group")
+
     @torch.no_grad()
     def step(self, closure=None, skip=()):
         """``skip``: parameters that took no part in this iteration's graph.  torch.optim.AdamW leaves a parameter whose ``.grad`` is None
-        untouched (no decay, no moment update); the fused kernel runs over the whole flat buffer, so their slices are put back after it."""
+        untouched (no decay, no moment update, its own step count stands still); the fused kernel runs over the whole flat buffer with
+        ONE step count, so skipped slices are put back after it, and a parameter that has fallen behind the shared count (``_lag``) and is
+        updated again is redone on its own slice with its own count (bias correction as torch computes it)."""
         if closure is not None:
             raise NotImplementedError("BemAdamW.step: closures are not supported")
-        keep = [(p, p.detach().clone(), self.state[p]["exp_avg"].clone(), self.state[p]["exp_avg_sq"].clone()) for p in skip]
+        skip = list(skip)
+        behind = [p for p in self._lag if self._lag[p] and not any(p is q for q in skip)]
+        keep = [(p, p.detach().clone(), self.state[p]["exp_avg"].clone(), self.state[p]["exp_avg_sq"].clone()) for p in skip + behind]
         self._steps += 1
         for group, f in zip(self.param_groups, self._flat):
             if f is None:
@@ -98,7 +132,13 @@ class BemAdamW(torch.optim.Optimizer):
                 self.state[p]["step"] += 1
         for p, val, m, v in keep:
             p.copy_(val); self.state[p]["exp_avg"].copy_(m); self.state[p]["exp_avg_sq"].copy_(v)
+        for p in skip:
             self.state[p]["step"] -= 1
+            self._lag[p] = self._lag.get(p, 0) + 1
+        for p in behind:
+            (fp, fg, fm, fv), group = self._slices(p)
+            ops.adamw_step_(fp, fg, fm, fv, group["lr"], group["betas"], group["eps"], group["weight_decay"], self._steps - self._lag[p],
+                            max_norm=self._max_norm, sumsq=self._sumsq if self._max_norm > 0 else None, norm_out=self._norm)
         self._max_norm = 0.0
         ops.bump_weight_epoch()        # parameters changed behind torch's version counters: derived-weight caches are stale
 
@@ -115,7 +155,7 @@ class BemAdamW(torch.optim.Optimizer):
         """Hyper-parameters via torch's loader, then the moments are copied INTO the flat buffers and the per-parameter state is pointed
         back at their views (torch's loader replaces the state tensors, which would detach them from the fused step)."""
         super().load_state_dict(state_dict)
-        steps = set()
+        own = []
         for f in self._flat:
             if f is None:
                 continue
@@ -126,13 +166,15 @@ class BemAdamW(torch.optim.Optimizer):
                 m, v = f["m"][off:off + n].view(p.shape), f["v"][off:off + n].view(p.shape)
                 if "exp_avg" in st:
                     m.copy_(st["exp_avg"]); v.copy_(st["exp_avg_sq"])
-                    steps.add(int(float(st["step"])))
-                else:
+                    k = int(float(st["step"]))
+                else:                                        # torch.optim.AdamW keeps no state for a parameter that never had a gradient
                     m.zero_(); v.zero_()
-                    steps.add(0)
-                self.state[p] = {"step": torch.tensor(float(max(steps))), "exp_avg": m, "exp_avg_sq": v}
+                    k = 0
+                own.append((p, k))
+                self.state[p] = {"step": torch.tensor(float(k)), "exp_avg": m, "exp_avg_sq": v}
                 off += _align4(n)
-        if len(steps) > 1:
-            raise ValueError(f"BemAdamW.load_state_dict: parameters at different step counts {sorted(steps)} (the fused step keeps one counter)")
-        self._steps = steps.pop() if steps else 0
+        # the fused step keeps ONE counter: the furthest parameter's; the others carry their distance to it (a parameter the step skipped,
+        # e.g. the Stage-I mask token after the first scheduler period -- condition_generator_model.py:185-186)
+        self._steps = max((k for _, k in own), default=0)
+        self._lag = {p: self._steps - k for p, k in own if k != self._steps}
         ops.bump_weight_epoch()

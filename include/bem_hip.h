@@ -302,6 +302,18 @@ int bem_gate_proj_x6_f32(const float* h, const float* dww, int64_t dww_bstride, 
                          const float* Wp, int64_t w_bstride, const float* bias, int64_t bias_bstride, const float* res,
                          float* out, int B, int Hd, int M, int H, int W, void* stream);
 
+/* The whole gdMlp branch of a VSSBlock in one kernel (vmamba.py:116-133 gdMlp.forward + the block's norm2 / residual :1330-1333):
+ *   out (B,C,H,W) = x + W_o (GELU(h[0:Hd]) * h[Hd:2Hd]) + b_o,   h = dw3x3(W_i LayerNorm2d(x) + b_i) + b_dw.
+ * Neither the 2Hd-channel project_in output nor the Hd-channel gate tensor reaches HBM (4 x 32 pixel tiles, both live as 16-gate-channel
+ * slices in LDS).  x (B,C,H,W) with C <= 80, out != x; ln_w / ln_b (C).
+ * Wp_gate = bem_pack_pw_weight_x6 of the (2Hd, C) project_in matrix in gate-interleaved row order: packed row 32 j + 2 c + s =
+ * W_i[s Hd + 16 j + c] (c < 16, s < 2; Hd % 16 == 0); bias_gate (Hd/16, 16, 2) = b_i in the same order (zeros for a layer without bias);
+ * dw_gate (Hd,9,2): [c][tap] = (dww[c][tap], dww[Hd + c][tap]); dwb_gate (Hd,2) = (dwb[c], dwb[Hd + c]) | NULL;
+ * Wp_out = bem_pack_pw_weight_x6 of the (C, Hd) project_out matrix; bias_out (C) | NULL.  Packed weights, bias_gate and dw_gate 16-byte aligned. */
+int bem_gdmlp_x6_f32(const float* x, const float* ln_w, const float* ln_b, float ln_eps, const float* Wp_gate,
+                     const float* bias_gate, const float* dw_gate, const float* dwb_gate, const float* Wp_out,
+                     const float* bias_out, float* out, int B, int C, int Hd, int H, int W, void* stream);
+
 /* gdMlp front half (vmamba.py:116-131 up to the gate, with the block's norm2 :1330) in one kernel:
  *   g (B,Hd,H,W) = GELU(h[0:Hd]) * h[Hd:2Hd],  h = dw3x3(W_i * LayerNorm2d(x) + b_i) + dwb.
  * x (B,C,H,W) with C <= 80 (8 x 32 pixel tiles up to C = 48, 4 x 32 beyond); ln_w / ln_b (C); Wp_gate = bem_pack_pw_weight_x6 of the (2Hd, C) project_in matrix whose rows were

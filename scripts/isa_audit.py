@@ -159,7 +159,9 @@ def audit_text(txt, fname):
                         if i < len(bits) and bits[i] == "1" and (regs_of(o) & from_lds) and regs_of(o) == dst:
                             lds_pk.append(l)
                             break
-            if ia and mn.startswith("global_load"):
+            if ia and mn.startswith("global_load_lds"):
+                pass                      # LDS-DMA: the first operand is the ADDRESS, read at issue; there is no VGPR destination to protect
+            elif ia and mn.startswith("global_load"):
                 pending |= dst
             elif ia and mn.startswith("s_waitcnt") and "vmcnt(0)" in l:
                 pending.clear()

@@ -637,6 +637,42 @@ def test_pi_gate_vs_unfused_chain(ops, cfg, monkeypatch):
     close(y, ref, 1e-4, 2e-5, f"pi_gate vs torch f64 {cfg}")
 
 
+@pytest.mark.parametrize("cfg", [(2, 40, 160, 16, 64, True), (4, 40, 160, 128, 128, True), (2, 24, 32, 13, 45, True), (1, 7, 16, 8, 32, False),
+                                 (3, 48, 96, 5, 3, True), (1, 16, 64, 33, 70, True), (2, 80, 320, 64, 64, True), (1, 64, 48, 9, 37, False),
+                                 (2, 72, 16, 4, 32, True), (1, 33, 16, 2, 31, True)])
+def test_gdmlp_x6_vs_chain_and_float64(ops, cfg):
+    """bem_gdmlp_x6_f32 (the whole gdMlp branch: LayerNorm + project_in + depthwise 3x3 + GELU gate + project_out + residual, the
+    2Hd- and Hd-channel tensors only in LDS) against the three-kernel chain and against torch in float64 (vmamba.py:116-133,1330-1333):
+    image borders inside and across the 4 x 32 tiles, ragged planes, C not a multiple of 16 / 32, no biases, both bench shapes."""
+    B, C, Hd, H, W, bias = cfg
+    g = torch.Generator().manual_seed(C * Hd + H)
+    x = torch.randn(B, C, H, W, generator=g) * 2 + 0.3
+    lw, lb = 1 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    wi = torch.randn(2 * Hd, C, generator=g) * C ** -0.5
+    bi = 0.3 * torch.randn(2 * Hd, generator=g) if bias else None
+    wd = torch.randn(2 * Hd, 1, 3, 3, generator=g) / 3
+    bd = 0.2 * torch.randn(2 * Hd, generator=g) if bias else None
+    wo = torch.randn(C, Hd, generator=g) * Hd ** -0.5
+    bo = 0.3 * torch.randn(C, generator=g) if bias else None
+    perm = ops.gate_interleave(Hd, "cpu")
+    Wg = ops.pack_pw_weight(dev(wi[perm].contiguous()), x6=True)
+    bg = dev(bi[perm].contiguous()) if bias else torch.zeros(2 * Hd, device="cuda")
+    wdg, bdg = ops.dw_gate_params(dev(wd), None if bd is None else dev(bd), Hd)
+    Wo = ops.pack_pw_weight(dev(wo), x6=True)
+    xg = dev(x)
+    y = ops.gdmlp_x6(xg, dev(lw), dev(lb), 1e-6, Wg, bg, wdg, bdg, Wo, None if bo is None else dev(bo), Hd)
+    t = ops.pw_gemm(xg, ops.pack_pw_weight(dev(wi), x6=True), 2 * Hd, ln=(dev(lw), dev(lb)), ln_eps=1e-6, bias=None if bi is None else dev(bi))
+    chain = ops.pw_gemm(ops.dwconv3x3(t, dev(wd), None if bd is None else dev(bd), 2), Wo, C, bias=None if bo is None else dev(bo), res=xg)
+    close(y, chain, 1e-4, 4e-5, f"gdmlp_x6 vs chain {cfg}")
+    xd = x.double()
+    mu, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
+    n = (xd - mu) / (var + 1e-6).sqrt() * lw.double()[None, :, None, None] + lb.double()[None, :, None, None]
+    tt = F.conv2d(n, wi.double()[:, :, None, None], None if bi is None else bi.double())
+    hh = F.conv2d(tt, wd.double(), None if bd is None else bd.double(), padding=1, groups=2 * Hd)
+    ref = (xd + F.conv2d(F.gelu(hh[:, :Hd]) * hh[:, Hd:], wo.double()[:, :, None, None], None if bo is None else bo.double())).float()
+    close(y, ref, 1e-4, 4e-5, f"gdmlp_x6 vs torch f64 {cfg}")
+
+
 @pytest.mark.parametrize("shape", [(2, 40, 128, 128, 3), (1, 80, 64, 64, 5), (2, 160, 32, 32, 10), (1, 6, 16, 64, 10), (1, 5, 256, 16, 5)])
 def test_ss2d_scan_row_major_form(ops, shape):
     """bem_ss2d_scan_rm (orientation 1 staged through LDS, y1 row-major) against the transposed-tensor form: identical
