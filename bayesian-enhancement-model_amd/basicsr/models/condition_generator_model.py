@@ -84,7 +84,13 @@ class ConditionGenerator(BaseModel):
         self.optimizer_g.zero_grad()
         if current_iter > self.opt["train"]["scheduler"]["periods"][0]:
             self.mask = None
-        _, preds = self.net_g(self.lq.contiguous(), mask=self.mask)
+        # the weight draws of iteration i come from Philox streams keyed by (manual_seed, rank, i): a resumed run draws what the
+        # uninterrupted run would have drawn (the reference's resumed run restarts torch's generator instead)
+        from bem.modules import _SAMPLE_CTX, SampleCtx, sampling
+        ctx = _SAMPLE_CTX[0] or SampleCtx(1, None, seed=int(self.opt.get("manual_seed") or 0) & 0xFFFFFFFF, rank=int(self.opt.get("rank", 0)),
+                                          epoch=int(current_iter) & 0xFFFFFF)          # an enclosing context (injected eps) wins
+        with sampling(ctx):
+            _, preds = self.net_g(self.lq.contiguous(), mask=self.mask)
         loss_dict = OrderedDict()
         l_kl = get_kl_loss(self.net_g)
         loss_dict["l_kl"] = l_kl.detach()

@@ -70,11 +70,13 @@ class SampleCtx:
 
     _epoch = 0      # process-wide forward counter: successive forwards never reuse a Philox stream
 
-    def __init__(self, nsets: int, eps: Optional[Dict[str, torch.Tensor]] = None, seed: int = 0, rank: int = 0):
+    def __init__(self, nsets: int, eps: Optional[Dict[str, torch.Tensor]] = None, seed: int = 0, rank: int = 0, epoch: Optional[int] = None):
         self.nsets, self.eps, self.seed, self.rank = nsets, eps, seed, rank
         self.counter = 0
-        SampleCtx._epoch += 1
-        self.epoch = SampleCtx._epoch
+        if epoch is None:
+            SampleCtx._epoch += 1
+            epoch = SampleCtx._epoch
+        self.epoch = int(epoch)              # a caller-chosen epoch (the training iteration) makes the draws a function of (seed, rank, iteration)
 
     def next_stream(self):
         """A fresh Philox stream id per sampled tensor: [rank : 16 bits | forward epoch : 24 bits | tensor counter : 20 bits].
@@ -431,12 +433,12 @@ class gdMlp(nn.Module):
             def prep():
                 perm = ops.gate_interleave(Hd, pi.weight.device)
                 bg = pi.bias.detach()[perm].contiguous() if pi.bias is not None else torch.zeros(2 * Hd, device=pi.weight.device)
-                return (ops.pack_pw_weight(pi.weight.detach().reshape(2 * Hd, C)[perm].contiguous(), x6=True), bg) + \
-                    ops.dw_gate_params(dw.weight.detach(), None if dw.bias is None else dw.bias.detach(), Hd) + \
-                    (ops.pack_pw_weight(po.weight.detach().reshape(po.out_channels, Hd).contiguous(), x6=True),
-                     None if po.bias is None else po.bias.detach().contiguous())
-            Wg, bg, w, bw, Wo, bo = self._cache.get("gdmlp_x6", [t for t in (pi.weight, pi.bias, dw.weight, dw.bias, po.weight, po.bias) if t is not None], prep)
-            return ops.gdmlp_x6(x, norm.weight.detach(), norm.bias.detach(), norm.eps, Wg, bg, w, bw, Wo, bo, Hd)
+                return (ops.pack_pw_weight(pi.weight.detach().reshape(2 * Hd, C)[perm].contiguous(), x6=True), bg,
+                        ops.dw_gate_params10(dw.weight.detach(), None if dw.bias is None else dw.bias.detach(), Hd),
+                        ops.pack_pw_weight(po.weight.detach().reshape(po.out_channels, Hd).contiguous(), x6=True),
+                        None if po.bias is None else po.bias.detach().contiguous())
+            Wg, bg, w10, Wo, bo = self._cache.get("gdmlp_x6", [t for t in (pi.weight, pi.bias, dw.weight, dw.bias, po.weight, po.bias) if t is not None], prep)
+            return ops.gdmlp_x6(x, norm.weight.detach(), norm.bias.detach(), norm.eps, Wg, bg, w10, Wo, bo, Hd)
         if PI_GATE and isinstance(self.project_in, PwConv2d) and isinstance(self.dwconv, DwConv2d) and ops.pi_gate_supported(C, Hd):
             # the 2Hd-channel project_in output lives only in LDS (bem_pi_gate_x6_f32); deterministic weights, C <= ops.PI_GATE_MAXC
             pi, dw = self.project_in, self.dwconv

@@ -87,7 +87,7 @@ SIGNATURES = {
     "bem_prelu_bwd_f32": [P, P, P, P, P, I64, P],
     "bem_bilinear_up_bwd_f32": [P, P, I, I, I, I, I, P],
     "bem_pi_gate_x6_f32": [P, P, P, F, P, P, P, P, P, I, I, I, I, I, P],
-    "bem_gdmlp_x6_f32": [P, P, P, F, P, P, P, P, P, P, P, I, I, I, I, I, P],
+    "bem_gdmlp_x6_f32": [P, P, P, F, P, P, P, P, P, P, I, I, I, I, I, P],
     "bem_conv3x3_x6_f32": [P, I64, P, P, P, P, P, I, I, I, I, I, I, P],
     "bem_conv4x4s2_x6_f32": [P, I64, P, P, P, P, P, I, I, I, I, I, I, P],
     "bem_conv_taps_x6_f32": [P, I64, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P],

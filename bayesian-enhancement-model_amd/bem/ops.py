@@ -371,18 +371,26 @@ def gdmlp_x6_supported(C, Hd):
     return USE_X6 and GDMLP_X6 and C <= GDMLP_X6_MAXC and Hd % 16 == 0
 
 
-def gdmlp_x6(x, ln_w, ln_b, ln_eps, Wp_gate, bias_gate, dww, dwb, Wp_out, bias_out, Hd):
+def dw_gate_params10(dww, dwb, Hd):
+    """depthwise (2Hd,1,3,3) / (2Hd)|None parameters -> the (Hd,10,2) block of bem_gdmlp_x6_f32: per gate channel nine (w1, w2) tap pairs
+    and the (b1, b2) bias pair (zeros without a bias) -- 80 bytes per channel, moved chunk-wise into LDS by the kernel."""
+    w = dww.reshape(2, Hd, 9).permute(1, 2, 0)
+    b = torch.zeros(Hd, 1, 2, device=dww.device, dtype=dww.dtype) if dwb is None else dwb.reshape(2, Hd).t().reshape(Hd, 1, 2)
+    return torch.cat([w, b], 1).contiguous()
+
+
+def gdmlp_x6(x, ln_w, ln_b, ln_eps, Wp_gate, bias_gate, dw10, Wp_out, bias_out, Hd):
     """x + project_out(GELU(h1) * h2) + b_o with [h1; h2] = dw3x3(project_in(LayerNorm2d(x))) in ONE kernel (bem_gdmlp_x6_f32).
     Wp_gate = pack_pw_weight(W_i[gate_interleave(Hd)], x6=True), bias_gate = b_i[gate_interleave(Hd)] (zeros without a bias);
-    dww, dwb = dw_gate_params(...); Wp_out = pack_pw_weight(W_o, x6=True)."""
-    for n_, t in (("x", x), ("ln_w", ln_w), ("ln_b", ln_b), ("Wp_gate", Wp_gate), ("bias_gate", bias_gate), ("dww", dww), ("Wp_out", Wp_out)):
+    dw10 = dw_gate_params10(...); Wp_out = pack_pw_weight(W_o, x6=True)."""
+    for n_, t in (("x", x), ("ln_w", ln_w), ("ln_b", ln_b), ("Wp_gate", Wp_gate), ("bias_gate", bias_gate), ("dw10", dw10), ("Wp_out", Wp_out)):
         _chk(t, n_)
-    _chk(dwb, "dwb", optional=True); _chk(bias_out, "bias_out", optional=True)
+    _chk(bias_out, "bias_out", optional=True)
     B, C, H, W = x.shape
     if not (USE_X6 and C <= 80 and Hd % 16 == 0):
         raise ValueError(f"gdmlp_x6: C = {C} (<= 80) / Hd = {Hd} (% 16) not supported")
-    if tuple(dww.shape) != (Hd, 9, 2) or (dwb is not None and tuple(dwb.shape) != (Hd, 2)):
-        raise ValueError("gdmlp_x6: depthwise parameters must come from dw_gate_params")
+    if tuple(dw10.shape) != (Hd, 10, 2):
+        raise ValueError("gdmlp_x6: depthwise parameters must come from dw_gate_params10")
     if ln_w.numel() != C or ln_b.numel() != C or bias_gate.numel() != 2 * Hd or (bias_out is not None and bias_out.numel() != C):
         raise ValueError("gdmlp_x6: parameter shapes")
     for Wp, (M, K), nm in ((Wp_gate, (2 * Hd, C), "Wp_gate"), (Wp_out, (C, Hd), "Wp_out")):
@@ -390,7 +398,7 @@ def gdmlp_x6(x, ln_w, ln_b, ln_eps, Wp_gate, bias_gate, dww, dwb, Wp_out, bias_o
             raise ValueError(f"gdmlp_x6: {nm} {tuple(Wp.shape)} does not match M={M} K={K} (x6 format, one weight set)")
     out = torch.empty_like(x)
     s = _timed("gdmlp_x6", 8.0 * x.numel(), 2.0 * B * H * W * (2 * Hd * C + Hd * C + 2 * Hd * 9)) if _PROF is not None else None
-    check(lib().bem_gdmlp_x6_f32(_p(x), _p(ln_w), _p(ln_b), float(ln_eps), _p(Wp_gate), _p(bias_gate), _p(dww), _p(dwb), _p(Wp_out),
+    check(lib().bem_gdmlp_x6_f32(_p(x), _p(ln_w), _p(ln_b), float(ln_eps), _p(Wp_gate), _p(bias_gate), _p(dw10), _p(Wp_out),
                                  _p(bias_out), _p(out), B, C, Hd, H, W, _stream()), "gdmlp_x6")
     _timed_end(s)
     return out

@@ -7,7 +7,7 @@
 // once (plus the halo rows from L2), out is written once, t exists as 32-row slices of one pixel tile in LDS and g as a 16-channel
 // slice that goes straight back into the matrix cores as the K-slice of project_out.
 //
-// Mapping (one workgroup = 4 waves = one 4 x 32 pixel tile of one image; 3 workgroups per CU for C <= 48, 2 beyond):
+// Mapping (one workgroup = 4 waves = one 4 x 32 pixel tile of one image; 2 workgroups per CU):
 //   * the tile's 6 x 34 halo is 204 pixels = 7 MFMA pixel blocks of 32; wave w owns blocks w and w + 4 and keeps their LayerNorm-ed
 //     input, split into three bf16 limbs (x6_common.h), in registers for the whole kernel.
 //   * project_in rows are packed by the host in gate-interleaved order: M-tile j row 2c + s = W_i[s Hd + 16 j + c], so that accumulator
@@ -20,23 +20,24 @@
 //                packed FMAs on (h1, h2), erf-form GELU evaluated two pixels at a time; g -> LDS as [pixel][16 channels];
 //       phase C  (runs with phase A of the NEXT chunk: both are matrix-core work) wave w takes pixel row w: its lanes read back the
 //                8 k-values of the B operand, split them into limbs and accumulate out[C x 32 px] += W_o[:, chunk] g.
-//     The chunk's packed weights (W_i chunk j+1, W_o chunk j, bias pairs) travel global -> LDS by LDS-DMA during phase B: no VGPRs,
-//     one copy per workgroup instead of one per wave.
+//     The chunk's parameters (packed W_i, W_o, bias pairs, depthwise taps + bias) travel global -> LDS by LDS-DMA: no VGPRs, one copy
+//     per workgroup instead of one per wave, double-buffered and requested one whole iteration ahead of their use.  Nothing in the
+//     chunk loop is fetched by a scalar or vector load.  The LDS regions are separate __shared__ objects, so the compiler may order
+//     the bias reads of phase A ahead of its T stores.
 //   * epilogue: + b_o + x (residual), 128-byte row segments per half-wave.
-// Two barriers per chunk; the workgroups of a CU drift apart, so one workgroup's matrix phase overlaps another's VALU phase.
+// Two barriers per chunk.
 #include "bem_common.h"
 #include "x6_common.h"
-#include <stdlib.h>
 
 namespace {
 
 struct GdX {
     const float* x; const float* ln_w; const float* ln_b; float ln_eps;
     const u32x4* Wpi;           // gate-interleaved project_in weights, x6-packed: [NCH][KB][3][64]
-    int64_t wpo_delta;          // project_out weights, x6-packed [MT][NCH][3][64], as a byte offset from Wpi (one base pointer: a select
-                                // between two pointer arguments is lowered through a stack slot)
+    const u32x4* Wpo;           // project_out weights, x6-packed [MT][NCH][3][64]
     const float* bgi;           // project_in bias as (h1, h2) pairs per gate channel: [NCH][16][2]  (zeros when the layer has no bias)
-    int C, Hd, H, W, NCH, tx, dbg;
+    const float* dw10;          // depthwise taps + bias per gate channel: [Hd][10] (w1, w2) pairs, slot 9 = (b1, b2)
+    int C, Hd, H, W, NCH, tx;
 };
 
 constexpr int GD_TH = 4, GD_TW = 32, GD_HW = GD_TW + 2;
@@ -47,12 +48,13 @@ constexpr int GD_GS = 20;                            // dwords per pixel row of 
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// one 1 KiB piece global -> LDS (lane l moves 16 bytes to lds_dst + 16 l); M0 carries the wave-uniform LDS byte address.
-// Not visible to the compiler's wait-count bookkeeping: the caller drains with s_waitcnt vmcnt(0) before the barrier that publishes it.
-__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+// one 1 KiB piece global -> LDS: lane l moves the 16 bytes at sbase + voff (voff = 16 l) to lds_dst + 16 l.  sbase is wave-uniform (an
+// SGPR pair: no per-lane 64-bit address arithmetic), M0 carries the wave-uniform LDS byte address.  Not visible to the compiler's
+// wait-count bookkeeping: the caller drains with s_waitcnt vmcnt(0) before the barrier that publishes the bytes.
+__device__ __forceinline__ void glds16(const void* sbase, uint32_t voff, uint32_t lds_dst) {
     uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 __device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)p; }   // low half of a generic LDS pointer = LDS offset
 
@@ -74,16 +76,15 @@ __device__ __forceinline__ f32x2 gelu_gate2(f32x2 a, f32x2 b) {
     return __builtin_elementwise_fma(h, s, h) * b;
 }
 
-template <int KBM, int MTO, int WPS>
-__global__ __launch_bounds__(256, WPS) void gdmlp_x6_kernel(GdX k, const float* __restrict__ dww, const float* __restrict__ dwb, float dbmul,
-                                                            const float* __restrict__ bpo, float bomul, float* __restrict__ out) {
-    constexpr int T_B = 16 * GD_TS * 8, G_B = 128 * GD_GS * 4, WI_B = KBM * 3 * 1024, WO_B = MTO * 3 * 1024;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[T_B + G_B + WI_B + WO_B + 128];
-    f32x2* const T = reinterpret_cast<f32x2*>(smem);                                   // [gate channel c][halo pixel] = (h1 input, h2 input)
-    float* const G = reinterpret_cast<float*>(smem + T_B);                             // [tile pixel][16 gate channels (+4 pad)]
-    const u32x4* const Wi = reinterpret_cast<const u32x4*>(smem + T_B + G_B);          // [kb][limb][lane]
-    const u32x4* const Wo = reinterpret_cast<const u32x4*>(smem + T_B + G_B + WI_B);   // [mt][limb][lane], directly behind Wi
-    const f32x2* const Bs = reinterpret_cast<const f32x2*>(smem + T_B + G_B + WI_B + WO_B);   // [16] bias pairs of the chunk in phase A
+template <int KBM, int MTO, int WOB>
+__global__ __launch_bounds__(256, 2) void gdmlp_x6_kernel(GdX k, const float* __restrict__ bpo, float bomul, float* __restrict__ out) {
+    constexpr int NPI = 3 * KBM, NPO = 3 * MTO;                                        // 1 KiB pieces of a W_i / W_o chunk
+    __shared__ __attribute__((aligned(16))) f32x2 T[16 * GD_TS];                       // [gate channel c][halo pixel] = (h1 input, h2 input)
+    __shared__ __attribute__((aligned(16))) float G[128 * GD_GS];                      // [tile pixel][16 gate channels (+4 pad)]
+    __shared__ __attribute__((aligned(16))) u32x4 Wis[2][NPI * 64];                    // W_i chunk [kb][limb][lane], chunk j in buffer j & 1
+    __shared__ __attribute__((aligned(16))) u32x4 Wos[WOB][NPO * 64];                  // W_o chunk [mt][limb][lane], chunk j in buffer j & (WOB - 1)
+    __shared__ __attribute__((aligned(16))) f32x2 Bss[2][16];                          // project_in bias pairs of the chunk
+    __shared__ __attribute__((aligned(16))) f32x2 DWs[2][16 * 10];                     // depthwise taps + bias of the chunk
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), kh = lane >> 5, n = lane & 31;
     const int b = blockIdx.z;
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
@@ -92,32 +93,37 @@ __global__ __launch_bounds__(256, WPS) void gdmlp_x6_kernel(GdX k, const float* 
     const int L = k.H * k.W;
     const float* xb = k.x + (int64_t)b * k.C * L;
 
-    // chunk weights by LDS-DMA: pieces 0 .. 3 KBM - 1 = W_i chunk ji, then 3 MTO pieces of W_o chunk jo (the two LDS regions are adjacent),
-    // then the bias pairs of ji (128 bytes: lanes 0..7).  Piece p is moved by wave p % 4; all selects are scalar.
-    const uint32_t wi_lds = lds_addr(Wi), bs_lds = lds_addr(Bs);
-    constexpr int NPI = 3 * KBM, NPC = NPI + 3 * MTO;
-    // piece p = wave + 4 t of this wave: its source moves by a fixed stride per chunk (W_i pieces follow chunk ji, W_o pieces chunk jo)
-    int64_t dsrc0[(NPC + 3) / 4];
+    // Chunk parameters by LDS-DMA, requested a whole iteration before their first use (the wait in front of an iteration's last barrier
+    // then finds them landed: waiting for a request made in the same half-iteration exposes ~1 us of loaded L2 latency per chunk, which
+    // was 95 % of this kernel's time).  Piece p of a chunk is moved by wave p % 4; all selects are scalar.
+    const uint32_t voff = 16 * lane;
+    const uint32_t wi_lds = lds_addr(Wis), wo_lds = lds_addr(Wos), bs_lds = lds_addr(Bss), dw_lds = lds_addr(DWs);
+    auto dma_in = [&](int ji, int buf) {                                               // W_i, bias pairs, depthwise parameters of chunk ji
 #pragma unroll
-    for (int t = 0; t < (NPC + 3) / 4; ++t) {
-        const int p = wave + 4 * t, q = p - NPI, mt = q / 3, li = q - 3 * mt;               // scalar
-        dsrc0[t] = p < NPI ? ((int64_t)p << 10) : k.wpo_delta + (((int64_t)mt * k.NCH * 3 + li) << 10);
-    }
-    auto dma_weights = [&](int ji, int jo) {
-#pragma unroll
-        for (int t = 0; t < (NPC + 3) / 4; ++t) {
+        for (int t = 0; t < (NPI + 3) / 4; ++t) {
             const int p = wave + 4 * t;
-            const int64_t off = dsrc0[t] + (p < NPI ? (int64_t)ji * (NPI << 10) : (int64_t)jo * (3 << 10));
-            if (p < NPC) glds16(reinterpret_cast<const u32x4*>((uintptr_t)k.Wpi + off) + lane, wi_lds + p * 1024);
+            if (p < NPI) glds16(k.Wpi + ((int64_t)ji * NPI + p) * 64, voff, wi_lds + (buf * NPI + p) * 1024);
         }
-        if (wave == (NPC & 3) && lane < 8) glds16(k.bgi + (int64_t)ji * 32 + 4 * lane, bs_lds);
+        if (wave == (NPI & 3)) {                                                       // the wave with the fewest W_i pieces
+            const float* src = k.dw10 + (int64_t)ji * 320;                             // 1280 bytes = one full piece + 16 lanes
+            glds16(src, voff, dw_lds + buf * 1280);
+            if (lane < 16) glds16(src + 256, voff, dw_lds + buf * 1280 + 1024);
+        }
+        if (wave == ((NPI + 1) & 3) && lane < 8) glds16(k.bgi + (int64_t)ji * 32, voff, bs_lds + buf * 128);
     };
-    dma_weights(0, 0);
-    for (int i = threadIdx.x; i < G_B / 16; i += 256) reinterpret_cast<f32x4*>(G)[i] = f32x4{0.f, 0.f, 0.f, 0.f};   // phase C of "chunk -1" adds zeros
+    auto dma_out = [&](int jo, int buf) {                                              // W_o chunk jo: MTO row blocks of three limbs
+#pragma unroll
+        for (int t = 0; t < (NPO + 3) / 4; ++t) {
+            const int p = wave + 4 * t, mt = p / 3, li = p - 3 * mt;
+            if (p < NPO) glds16(k.Wpo + (((int64_t)mt * k.NCH + jo) * 3 + li) * 64, voff, wo_lds + (buf * NPO + p) * 1024);
+        }
+    };
+    dma_in(0, 0);
 
     // ---- this wave's halo pixel blocks (w, w + 4): load, LayerNorm over channels, zero outside the image, split into limbs
     u32x4 xl[2][KBM][3];
     float msk[2];
+    uint32_t mbit[2];                  // all ones inside the image
     int hpo[2];
     {
         float lnw[KBM][8], lnb[KBM][8];
@@ -138,6 +144,7 @@ __global__ __launch_bounds__(256, WPS) void gdmlp_x6_kernel(GdX k, const float* 
             const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
             const bool in = hp < GD_NPH && gy >= 0 && gy < k.H && gx >= 0 && gx < k.W && (wave + 4 * i) < GD_NPB;
             msk[i] = in ? 1.f : 0.f;
+            mbit[i] = in ? 0xffffffffu : 0u;
             const int off = min(max(gy, 0), k.H - 1) * k.W + min(max(gx, 0), k.W - 1);
             float xr[KBM][8];
 #pragma unroll
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(256, WPS) void gdmlp_x6_kernel(GdX k, const float* 
 #pragma unroll
         for (int r = 0; r < 16; ++r) oh[mt][r] = 0.f;
 
-    auto phase_c = [&]() {
+    auto phase_c = [&](const u32x4* Wo) {
         const float* gp = G + (wave * 32 + n) * GD_GS + 8 * kh;
         const f32x4 ga = *reinterpret_cast<const f32x4*>(gp), gb = *reinterpret_cast<const f32x4*>(gp + 4);
         const float v[8] = {ga[0], ga[1], ga[2], ga[3], gb[0], gb[1], gb[2], gb[3]};
@@ -209,45 +216,58 @@ __global__ __launch_bounds__(256, WPS) void gdmlp_x6_kernel(GdX k, const float* 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+#pragma clang loop unroll(disable)
     for (int j = 0; j < k.NCH; ++j) {
+        const int cur = j & 1;
+        // requests for the next iteration (W_i, bias, depthwise parameters of chunk j + 1) and, with two W_o buffers, for phase C of this
+        // chunk: their buffers were last read before the previous iteration's final barrier
+        if (j + 1 < k.NCH) dma_in(j + 1, cur ^ 1);
+        if (WOB == 2) dma_out(j, cur);
+        const u32x4* const Wi = Wis[cur];
         // ---- phase A (chunk j) and phase C (chunk j - 1): matrix-core work
-        if (!(k.dbg & 1)) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                if (wave + 4 * i < GD_NPB) {                                           // wave-uniform
-                    f32x16 hi, lo;
+        for (int i = 0; i < 2; ++i) {
+            if (wave + 4 * i < GD_NPB) {                                               // wave-uniform
+                // accumulator rows 2(q&1) + 8(q>>1) + 4kh (+1) are the (h1, h2) inputs of gate channel c = (q&1) + 4(q>>1) + 2kh:
+                // the small-product accumulator starts from the channel's bias pair (zero outside the image: the conv pads t with zeros)
+                f32x16 hi, lo;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) hi[r] = lo[r] = 0.f;
-#pragma unroll
-                    for (int kb = 0; kb < KBM; ++kb) {
-                        const u32x4* wp = Wi + kb * 192 + lane;
-                        const u32x4 wl[3] = {wp[0], wp[64], wp[128]};
-                        mac6(wl, xl[i][kb], hi, lo);
-                    }
-                    f32x2* tp = T + 2 * kh * GD_TS + hpo[i];
-                    const f32x2 m2 = {msk[i], msk[i]};
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        // accumulator rows 2(q&1) + 8(q>>1) + 4kh (+1): the (h1, h2) inputs of gate channel c = (q&1) + 4(q>>1) + 2kh
-                        const int c = (q & 1) + 4 * (q >> 1);
-                        const f32x2 bp = Bs[c + 2 * kh];
-                        const f32x2 sum = f32x2{hi[2 * q], hi[2 * q + 1]} + f32x2{lo[2 * q], lo[2 * q + 1]};
-                        tp[c * GD_TS] = __builtin_elementwise_fma(bp, m2, sum);
-                    }
+                for (int q = 0; q < 8; ++q) {
+                    const f32x2 bp = Bss[cur][(q & 1) + 4 * (q >> 1) + 2 * kh];
+                    lo[2 * q] = bitsf(fbits(bp[0]) & mbit[i]);
+                    lo[2 * q + 1] = bitsf(fbits(bp[1]) & mbit[i]);
+                    hi[2 * q] = hi[2 * q + 1] = 0.f;
                 }
+#pragma unroll
+                for (int kb = 0; kb < KBM; ++kb) {
+                    const u32x4* wp = Wi + kb * 192 + lane;
+                    const u32x4 wl[3] = {wp[0], wp[64], wp[128]};
+                    hi = mfma16(wl[0], xl[i][kb][0], hi);
+                    lo = mfma16(wl[0], xl[i][kb][2], lo);
+                    lo = mfma16(wl[2], xl[i][kb][0], lo);
+                    lo = mfma16(wl[1], xl[i][kb][1], lo);
+                    lo = mfma16(wl[0], xl[i][kb][1], lo);
+                    lo = mfma16(wl[1], xl[i][kb][0], lo);
+                }
+                f32x2* tp = T + 2 * kh * GD_TS + hpo[i];
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    tp[((q & 1) + 4 * (q >> 1)) * GD_TS] = f32x2{hi[2 * q] + lo[2 * q], hi[2 * q + 1] + lo[2 * q + 1]};
             }
         }
-        if (!(k.dbg & 4)) phase_c();
+        if (j) phase_c(Wos[(j - 1) & (WOB - 1)]);
         __syncthreads();
-        // ---- the next chunk's weights start moving; phase B (chunk j)
-        dma_weights(min(j + 1, k.NCH - 1), j);
-        if (!(k.dbg & 2)) {
+        // ---- phase B (chunk j); with one W_o buffer its chunk is requested now that phase C has released the buffer
+        if (WOB == 1) dma_out(j, 0);
+        {
             f32x2 g[4];                                                                // [channel] = (pixel row 2kh, pixel row 2kh + 1)
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
-                const int cg = 16 * j + c_lo + cc;
-                const f32x2* wq = reinterpret_cast<const f32x2*>(dww) + cg * 9;          // host-interleaved (w1, w2) per tap
-                const f32x2 bias = reinterpret_cast<const f32x2*>(dwb)[cg] * dbmul;
+                const f32x4* wv = reinterpret_cast<const f32x4*>(DWs[cur] + (c_lo + cc) * 10);   // wave-uniform address: broadcast reads
+                const f32x4 w01 = wv[0], w23 = wv[1], w45 = wv[2], w67 = wv[3], w8b = wv[4];
+                const f32x2 wq[9] = {{w01[0], w01[1]}, {w01[2], w01[3]}, {w23[0], w23[1]}, {w23[2], w23[3]}, {w45[0], w45[1]},
+                                     {w45[2], w45[3]}, {w67[0], w67[1]}, {w67[2], w67[3]}, {w8b[0], w8b[1]}};
+                const f32x2 bias = {w8b[2], w8b[3]};
                 const f32x2* tp = T + (c_lo + cc) * GD_TS + wb_lds;
                 f32x2 win[4][3];
 #pragma unroll
@@ -271,7 +291,7 @@ __global__ __launch_bounds__(256, WPS) void gdmlp_x6_kernel(GdX k, const float* 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    if (!(k.dbg & 4)) phase_c();
+    phase_c(Wos[(k.NCH - 1) & (WOB - 1)]);
 
     // ---- epilogue: + bias + residual, rows (r & 3) + 8 (r >> 2) + 4 kh of each M-tile, 128-byte segments per half-wave
     if (oy < k.H && ox < k.W) {
@@ -291,32 +311,32 @@ __global__ __launch_bounds__(256, WPS) void gdmlp_x6_kernel(GdX k, const float* 
 }  // namespace
 
 extern "C" int bem_gdmlp_x6_f32(const float* x, const float* ln_w, const float* ln_b, float ln_eps, const float* Wp_gate,
-                                const float* bias_gate, const float* dw_gate, const float* dwb_gate, const float* Wp_out,
+                                const float* bias_gate, const float* dw_gate10, const float* Wp_out,
                                 const float* bias_out, float* out, int B, int C, int Hd, int H, int W, void* stream) {
-    BEM_REQUIRE(x && ln_w && ln_b && Wp_gate && bias_gate && dw_gate && Wp_out && out, "gdmlp_x6: null tensor");
+    BEM_REQUIRE(x && ln_w && ln_b && Wp_gate && bias_gate && dw_gate10 && Wp_out && out, "gdmlp_x6: null tensor");
     BEM_REQUIRE(B >= 0 && B <= 65535 && C > 0 && C <= 80 && Hd > 0 && Hd % 16 == 0 && H > 0 && W > 0,
                 "gdmlp_x6: needs C <= 80 and Hd %% 16 == 0 (got C = %d, Hd = %d)", C, Hd);
-    BEM_REQUIRE((((uintptr_t)Wp_gate | (uintptr_t)Wp_out | (uintptr_t)bias_gate | (uintptr_t)dw_gate) & 15) == 0,
-                "gdmlp_x6: packed weights, bias pairs and depthwise weights must be 16-byte aligned");
+    BEM_REQUIRE((((uintptr_t)Wp_gate | (uintptr_t)Wp_out | (uintptr_t)bias_gate | (uintptr_t)dw_gate10) & 15) == 0,
+                "gdmlp_x6: packed weights, bias pairs and depthwise parameters must be 16-byte aligned");
     BEM_REQUIRE(x != out, "gdmlp_x6: in-place operation is not supported (halo reads)");
     BEM_REQUIRE((int64_t)C * H * W < (1ll << 31), "gdmlp_x6: plane set too large for 32-bit offsets");
     if (B == 0) return BEM_OK;
     GdX k;
     k.x = x; k.ln_w = ln_w; k.ln_b = ln_b; k.ln_eps = ln_eps;
-    k.Wpi = reinterpret_cast<const u32x4*>(Wp_gate); k.wpo_delta = (int64_t)((uintptr_t)Wp_out - (uintptr_t)Wp_gate); k.bgi = bias_gate;
+    k.Wpi = reinterpret_cast<const u32x4*>(Wp_gate); k.Wpo = reinterpret_cast<const u32x4*>(Wp_out); k.bgi = bias_gate;
+    k.dw10 = dw_gate10;
     k.C = C; k.Hd = Hd; k.H = H; k.W = W; k.NCH = Hd / 16; k.tx = cdiv(W, GD_TW);
-    k.dbg = getenv("BEM_GDX_DBG") ? atoi(getenv("BEM_GDX_DBG")) : 0;
-    // absent biases: read an always-present array and multiply by zero -- no branch next to a load
-    const float* dwbp = dwb_gate ? dwb_gate : dw_gate;
+    // absent output bias: read an always-present array and multiply by zero -- no branch next to a load
     const float* bpop = bias_out ? bias_out : ln_w;
-    const float dbmul = dwb_gate ? 1.f : 0.f, bomul = bias_out ? 1.f : 0.f;
+    const float bomul = bias_out ? 1.f : 0.f;
     dim3 grid(k.tx * cdiv(H, GD_TH), 1, B);
     hipStream_t s = (hipStream_t)stream;
     const int KB = cdiv(C, 16);
-    if (KB == 1) gdmlp_x6_kernel<1, 1, 3><<<grid, 256, 0, s>>>(k, dw_gate, dwbp, dbmul, bpop, bomul, out);
-    else if (KB == 2) gdmlp_x6_kernel<2, 1, 3><<<grid, 256, 0, s>>>(k, dw_gate, dwbp, dbmul, bpop, bomul, out);
-    else if (KB == 3) gdmlp_x6_kernel<3, 2, 3><<<grid, 256, 0, s>>>(k, dw_gate, dwbp, dbmul, bpop, bomul, out);
-    else if (KB == 4) gdmlp_x6_kernel<4, 2, 2><<<grid, 256, 0, s>>>(k, dw_gate, dwbp, dbmul, bpop, bomul, out);
-    else gdmlp_x6_kernel<5, 3, 2><<<grid, 256, 0, s>>>(k, dw_gate, dwbp, dbmul, bpop, bomul, out);
+    // two workgroups per CU in every variant (LDS: T 26 KB + G 10 KB + two W_i buffers + one or two W_o buffers <= 80 KB)
+    if (KB == 1) gdmlp_x6_kernel<1, 1, 2><<<grid, 256, 0, s>>>(k, bpop, bomul, out);
+    else if (KB == 2) gdmlp_x6_kernel<2, 1, 2><<<grid, 256, 0, s>>>(k, bpop, bomul, out);
+    else if (KB == 3) gdmlp_x6_kernel<3, 2, 2><<<grid, 256, 0, s>>>(k, bpop, bomul, out);
+    else if (KB == 4) gdmlp_x6_kernel<4, 2, 2><<<grid, 256, 0, s>>>(k, bpop, bomul, out);
+    else gdmlp_x6_kernel<5, 3, 1><<<grid, 256, 0, s>>>(k, bpop, bomul, out);
     return bem_check_launch("gdmlp_x6");
 }

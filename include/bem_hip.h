@@ -308,10 +308,11 @@ int bem_gate_proj_x6_f32(const float* h, const float* dww, int64_t dww_bstride, 
  * slices in LDS).  x (B,C,H,W) with C <= 80, out != x; ln_w / ln_b (C).
  * Wp_gate = bem_pack_pw_weight_x6 of the (2Hd, C) project_in matrix in gate-interleaved row order: packed row 32 j + 2 c + s =
  * W_i[s Hd + 16 j + c] (c < 16, s < 2; Hd % 16 == 0); bias_gate (Hd/16, 16, 2) = b_i in the same order (zeros for a layer without bias);
- * dw_gate (Hd,9,2): [c][tap] = (dww[c][tap], dww[Hd + c][tap]); dwb_gate (Hd,2) = (dwb[c], dwb[Hd + c]) | NULL;
- * Wp_out = bem_pack_pw_weight_x6 of the (C, Hd) project_out matrix; bias_out (C) | NULL.  Packed weights, bias_gate and dw_gate 16-byte aligned. */
+ * dw_gate10 (Hd,10,2): [c][tap < 9] = (dww[c][tap], dww[Hd + c][tap]), [c][9] = (dwb[c], dwb[Hd + c]) (zeros for a layer without bias);
+ * Wp_out = bem_pack_pw_weight_x6 of the (C, Hd) project_out matrix; bias_out (C) | NULL.  Packed weights, bias_gate and dw_gate10 16-byte
+ * aligned: the kernel moves them chunk by chunk into LDS with LDS-DMA (global_load_lds_dwordx4). */
 int bem_gdmlp_x6_f32(const float* x, const float* ln_w, const float* ln_b, float ln_eps, const float* Wp_gate,
-                     const float* bias_gate, const float* dw_gate, const float* dwb_gate, const float* Wp_out,
+                     const float* bias_gate, const float* dw_gate10, const float* Wp_out,
                      const float* bias_out, float* out, int B, int C, int Hd, int H, int W, void* stream);
 
 /* gdMlp front half (vmamba.py:116-131 up to the gate, with the block's norm2 :1330) in one kernel:

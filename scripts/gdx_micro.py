@@ -1,5 +1,5 @@
 """bem_gdmlp_x6_f32 at the bench's level-0 / level-1 shapes: parity against the unfused chain, time of the fused kernel, of the chain's kernels
-and of the fused kernel with phases disabled (BEM_GDX_DBG: 1 no phase A, 2 no phase B, 4 no phase C).   python scripts/gdx_micro.py [reps]"""
+(BEM_GDX_WPS=2: the C <= 48 form at two workgroups per CU).   python scripts/gdx_micro.py [reps]"""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bayesian-enhancement-model_amd"))
 from bem import ops
@@ -28,11 +28,11 @@ for (B, C, H, W) in [(64, 40, 128, 128), (64, 80, 64, 64), (64, 160, 32, 32)]:
     Wg = ops.pack_pw_weight(wi[perm].contiguous(), x6=True); bg = bi[perm].contiguous()
     wdg, bdg = ops.dw_gate_params(wd, bd, Hd)
     Wo = ops.pack_pw_weight(wo, x6=True); Wi = ops.pack_pw_weight(wi, x6=True)
-    fused = lambda: ops.gdmlp_x6(x, lw, lb, 1e-6, Wg, bg, wdg, bdg, Wo, bo, Hd)
+    w10 = ops.dw_gate_params10(wd, bd, Hd)
+    fused = lambda: ops.gdmlp_x6(x, lw, lb, 1e-6, Wg, bg, w10, Wo, bo, Hd)
     def chain():
         t = ops.pw_gemm(x, Wi, 2 * Hd, ln=(lw, lb), ln_eps=1e-6, bias=bi)
         return ops.pw_gemm(ops.dwconv3x3(t, wd, bd, 2), Wo, C, bias=bo, res=x)
-    os.environ["BEM_GDX_DBG"] = "0"
     y, r = fused(), chain()
     err = (y - r).abs().max().item()
     print(f"C={C} {H}x{W}: max |fused - chain| = {err:.3e} (|chain| max {r.abs().max().item():.2f})")
@@ -42,7 +42,4 @@ for (B, C, H, W) in [(64, 40, 128, 128), (64, 80, 64, 64), (64, 160, 32, 32)]:
         Wg2 = ops.pack_pw_weight(wi[perm2].contiguous(), x6=True); bg2 = bi[perm2].contiguous()
         pig = lambda: ops.pw_gemm(ops.pi_gate(x, lw, lb, 1e-6, Wg2, bg2, wdg, bdg, Hd), Wo, C, bias=bo, res=x)
         print(f"  pi_gate + project_out: {timeit(pig):8.1f} us")
-    for dbg in (0, 1, 2, 4, 3, 5, 6, 7):
-        os.environ["BEM_GDX_DBG"] = str(dbg)
-        print(f"  fused dbg={dbg}: {timeit(fused):8.1f} us")
-    os.environ["BEM_GDX_DBG"] = "0"
+    print(f"  fused: {timeit(fused):8.1f} us")

@@ -103,3 +103,54 @@ def test_select_guards_all_zero_scores():
     assert select_best(torch.zeros(6), 3) == [0, 0]
     # ties -> first index; a negative maximum flips the ratio order exactly as psnr / max(psnr) does in eval.py:284
     assert select_best(torch.tensor([1.0, 3.0, 3.0, -2.0, -1.0, -1.0]), 3) == [1, 0]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# sample-major sharding (the eval driver's B = 1: the N samples of one image split over the ranks)
+# ------------------------------------------------------------------------------------------------------------------
+def _stub_candidates(imgs, targets, n_local, sample_offset=0, total_samples=None, **kw):
+    """BEMPipeline.candidates' contract on a closed form: candidate n of an image depends on (image, n) only, so the samples a rank
+    draws for its block [offset, offset + n_local) are the same tensors the unsharded call produces for those indices."""
+    N = total_samples or n_local
+    b = imgs.shape[0]
+    scale = torch.linspace(0.6, 1.4, N)[sample_offset:sample_offset + n_local].view(1, n_local, 1, 1, 1)
+    final = (imgs[:, None] * scale).clamp(0, 1)
+    mse = ((final - targets[:, None]) ** 2).mean(dim=(2, 3, 4))
+    psnr = 10 * torch.log10(1 / mse)
+    psnr[imgs[:, 0, 0, 0] > 0.5] = 20.0                              # an image whose candidates all tie: the first index must win
+    return dict(final=final.reshape(b * n_local, *imgs.shape[1:]), psnr=psnr.reshape(b * n_local))
+
+
+def _sample_worker(rank, world, port, n_images, N, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bem.dist import enhance_sample_sharded, gather_samples, shard_samples
+    g = torch.Generator().manual_seed(11)
+    imgs = torch.rand(n_images, 3, 6, 5, generator=g) * 0.5
+    imgs[-1, 0, 0, 0] = 0.9                                          # the tie image
+    tg = (imgs * 1.2).clamp(0, 1)
+    full = _stub_candidates(imgs, tg, N)
+    s = full["psnr"].view(n_images, N)
+    ref_best = [row.index(max(row)) for row in s.tolist()]
+    ref_img = full["final"].view(n_images, N, 3, 6, 5)[torch.arange(n_images), torch.tensor(ref_best)]
+    ok = True
+    # the gather puts every (image, sample) row where the unsharded call has it
+    lo, hi = shard_samples(N, rank, world)
+    mine = _stub_candidates(imgs, tg, hi - lo, sample_offset=lo, total_samples=N) if hi > lo else dict(final=imgs.new_zeros((0, 3, 6, 5)))
+    ok = ok and torch.equal(gather_samples(mine["final"], n_images, N, rank, world), full["final"])
+    for mode in ("candidates", "scores"):
+        img, best = enhance_sample_sharded(_stub_candidates, imgs, tg, N, rank, world, mode=mode)
+        ok = ok and best.tolist() == ref_best and torch.equal(img, ref_img)
+    ret[rank] = ok
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_images,N", [(1, 5), (2, 4), (1, 1)])
+def test_sample_major_sharding_equals_unsharded_world2(n_images, N):
+    """B = 1 with N = 5 (ragged blocks 3 + 2), B = 2 with even blocks, and N = 1 < world (an empty block joins the collectives):
+    selected image and index equal the unsharded first-maximum rule (eval.py:284-285), ties included."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_sample_worker, args=(world, 29700 + 10 * n_images + N, n_images, N, ret), nprocs=world, join=True)
+    assert all(ret[r] for r in range(world))

@@ -657,10 +657,10 @@ def test_gdmlp_x6_vs_chain_and_float64(ops, cfg):
     perm = ops.gate_interleave(Hd, "cpu")
     Wg = ops.pack_pw_weight(dev(wi[perm].contiguous()), x6=True)
     bg = dev(bi[perm].contiguous()) if bias else torch.zeros(2 * Hd, device="cuda")
-    wdg, bdg = ops.dw_gate_params(dev(wd), None if bd is None else dev(bd), Hd)
+    w10 = ops.dw_gate_params10(dev(wd), None if bd is None else dev(bd), Hd)
     Wo = ops.pack_pw_weight(dev(wo), x6=True)
     xg = dev(x)
-    y = ops.gdmlp_x6(xg, dev(lw), dev(lb), 1e-6, Wg, bg, wdg, bdg, Wo, None if bo is None else dev(bo), Hd)
+    y = ops.gdmlp_x6(xg, dev(lw), dev(lb), 1e-6, Wg, bg, w10, Wo, None if bo is None else dev(bo), Hd)
     t = ops.pw_gemm(xg, ops.pack_pw_weight(dev(wi), x6=True), 2 * Hd, ln=(dev(lw), dev(lb)), ln_eps=1e-6, bias=None if bi is None else dev(bi))
     chain = ops.pw_gemm(ops.dwconv3x3(t, dev(wd), None if bd is None else dev(bd), 2), Wo, C, bias=None if bo is None else dev(bo), res=xg)
     close(y, chain, 1e-4, 4e-5, f"gdmlp_x6 vs chain {cfg}")

