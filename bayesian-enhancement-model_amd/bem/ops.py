@@ -397,7 +397,7 @@ def gdmlp_x6(x, ln_w, ln_b, ln_eps, Wp_gate, bias_gate, dw10, Wp_out, bias_out, 
         if Wp.dim() != 2 or Wp.shape[0] != 1 or Wp.shape[1] != packed_elems(M, K, True) or getattr(Wp, "_bem_mk", (M, K)) != (M, K):
             raise ValueError(f"gdmlp_x6: {nm} {tuple(Wp.shape)} does not match M={M} K={K} (x6 format, one weight set)")
     out = torch.empty_like(x)
-    s = _timed("gdmlp_x6", 8.0 * x.numel(), 2.0 * B * H * W * (2 * Hd * C + Hd * C + 2 * Hd * 9)) if _PROF is not None else None
+    s = _timed("gdmlp_x6", 8.0 * x.numel(), 6.0 * 2.0 * B * H * W * (2 * Hd * C + Hd * C)) if _PROF is not None and _PROF["kernel"] == "gdmlp_x6" and _PROF["pred"](C) else None
     check(lib().bem_gdmlp_x6_f32(_p(x), _p(ln_w), _p(ln_b), float(ln_eps), _p(Wp_gate), _p(bias_gate), _p(dw10), _p(Wp_out),
                                  _p(bias_out), _p(out), B, C, Hd, H, W, _stream()), "gdmlp_x6")
     _timed_end(s)
@@ -1201,7 +1201,11 @@ _KEYS = {
     "pw_gemm": ("pw_gemm", "mfma", "pw_gemm* (all variants)", lambda K, M, ln, L, mode: True),
     "gdmlp_fused": ("gdmlp_fused", "mfma", "gdmlp_fused_kernel", None),
     # the whole gdMlp branch in one kernel: x in, out out -- 8 bytes per element of x are its algorithmic bytes
-    "gdmlp_x6": ("gdmlp_x6", "hbm", "gdmlp_x6_kernel<3, 2, 3>", None),
+    # (HBM: 42 us at level 0) -- but its two GEMMs (2Hd x C and C x Hd per pixel) evaluated as six bf16 limb products are 242 GFLOP on the
+    # matrix cores (97 us at the dense bf16 peak): the matrix pipe is the roofline that bounds it.  flops = 6 x the f32 GEMM flops
+    # (what the x6 scheme must issue for the output pixels; halo and padding MFMAs are waste, not work).
+    "gdmlp_x6<3>": ("gdmlp_x6", "mfma_bf16", "gdmlp_x6_kernel<3, 2, 2>", lambda C: 32 < C <= 48),
+    "gdmlp_x6<5>": ("gdmlp_x6", "mfma_bf16", "gdmlp_x6_kernel<5, 3, 1>", lambda C: 64 < C <= 80),
     "conv2d": ("conv2d", "mfma", "conv2d_kernel", None),
     "dwconv3x3": ("dwconv3x3", "hbm", "dwconv3x3_kernel", None),
     "ss2d_scan": ("ss2d_scan", "hbm", "ss2d_scan_kernel", None),

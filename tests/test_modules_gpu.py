@@ -369,3 +369,63 @@ def test_archs_build_and_run_with_every_decomp_model(yml, dm):
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     ref = (O.ddwavelet_ref if "Wavelet" in yml else O.singlebranch_ref)(sd, x, O.selective_scan_c, **({"decomp_model": dm}))
     close(out, ref, 2e-3, 1e-4, f"{yml} {dm}")
+
+
+def test_full_width_stochastic_mc_vs_oracle():
+    """The headline path at FULL WIDTH with stochastic weights: n_feat 40, blocks [2,2,2], shipped QD model4 decomposition, one 64x64 image,
+    N = 4 Bayesian samples with injected weight epsilons and condition noise (eval.py:199-297, image_enhancer_model.py:165-216).  Every
+    candidate's PSNR must agree with oracle.eval_mc_ref within 1e-3 dB (the north star's bar), candidates to 5e-4, same selected index."""
+    from bem.pipeline import BEMPipeline, build_nets, synthetic_pair
+    net1, net2 = build_nets(device="cuda")
+    sd1 = {k: v.detach().cpu() for k, v in net1.state_dict().items()}
+    sd2 = {k: v.detach().cpu() for k, v in net2.state_dict().items()}
+    lq, gt = synthetic_pair((1, 3, 64, 64), seed=11)
+    N = 4
+    g = torch.Generator().manual_seed(21)
+    eps_cpu = [{(k[:-len("mu_weight")] + "weight" if k.endswith("mu_weight") else k[:-len("mu_bias")] + "bias"): torch.randn(v.shape, generator=g)
+                for k, v in sd1.items() if k.endswith(("mu_weight", "mu_bias"))} for _ in range(N)]
+    noise = torch.randn(N, 3, 4, 4, generator=g)
+    ref = O.eval_mc_ref(sd1, sd2, lq, gt, N, gt_mean=True, eps_list=eps_cpu, noise_list=[noise[i:i + 1] for i in range(N)], scan=O.selective_scan_c)
+    r = BEMPipeline(net1, net2, 16, 0.1).enhance(lq.cuda(), gt.cuda(), N, gt_mean=True, eps={k: torch.stack([e[k] for e in eps_cpu]).cuda() for k in eps_cpu[0]},
+                                                noise=noise.cuda())
+    fin = r["final"].cpu()
+    for i in range(N):
+        d = float((fin[i].permute(1, 2, 0) - torch.from_numpy(ref["finals"][i])).abs().max())
+        assert d < 5e-4, (i, d)
+    dps = np.abs(np.asarray(ref["psnr"]) - r["psnr"].cpu().numpy())
+    assert dps.max() < 1e-3, dps                                     # dB
+    s = sorted(ref["psnr"], reverse=True)
+    if s[0] - s[1] > 1e-3:
+        assert int(r["best"][0]) == int(ref["best"])
+    # the samples are different draws: the candidates must not coincide
+    assert float((fin[0] - fin[1]).abs().max()) > 1e-4
+
+
+def test_exchange_and_select_on_rccl_world1():
+    """bem.dist on the `nccl` (= RCCL) backend with one rank: the all_gather_into_tensor form of the exchange runs on the device, and
+    both exchange modes return the unsharded selection (N > 1 ranks are covered on gloo in tests/test_dist_cpu.py)."""
+    import torch.distributed as dist
+    from bem import dist as bdist
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        g = torch.Generator().manual_seed(2)
+        Bn, N = 3, 4
+        final = torch.rand(Bn * N, 3, 8, 6, generator=g).cuda()
+        score = torch.rand(Bn * N, generator=g).cuda()
+        score[4:8] = 0.5                                              # a tie image: first index wins
+        ref_best = [int(torch.argmax(score[i * N:(i + 1) * N].cpu())) for i in range(Bn)]
+        ref_best[1] = 0
+        for mode in ("candidates", "scores"):
+            img, best = bdist.exchange_and_select(final, score, N, 1, mode)
+            assert best.tolist() == ref_best
+            assert torch.equal(img, final.view(Bn, N, 3, 8, 6)[torch.arange(Bn), torch.tensor(ref_best)])
+        # the collective itself, in the backend's tensor form (all_gather_into_tensor over RCCL), on both payloads of the exchange
+        assert dist.get_backend() == "nccl"
+        assert torch.equal(bdist._all_gather_rows(final, 1), final) and torch.equal(bdist._all_gather_rows(score, 1), score)
+        assert torch.equal(bdist.gather_samples(final, Bn, N, 0, 1), final)
+    finally:
+        dist.destroy_process_group()

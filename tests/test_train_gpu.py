@@ -645,3 +645,74 @@ def test_training_driver_save_resume_reproduces_the_run(dev, tmp_path, yml, firs
     assert worst <= 4e-5, worst                              # a run resumed with zeroed moments or a shifted batch order differs by ~ lr = 2e-4 per step
     # the run moved: parameters differ from the initial seed-100 net by many learning rates
     assert (st / f"{(total // 3) * 3}.state").is_file()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE config 4 at its real size (B 16, 256x256, n_feat 40): the dispatch the bench runs
+# ------------------------------------------------------------------------------------------------------------------
+def _cfg4():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("cfg4_grads", os.path.join(os.path.dirname(PKG), "scripts", "cfg4_grads.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_config4_full_size_default_dispatch_vs_generic_kernels(dev, tmp_path):
+    """One ImageEnhancer forward / backward at B 16, 256x256, full width, in the DEFAULT dispatch (x6 weight gradients on every launch of
+    >= 16384 pixels, the L = 16384 / 4096 / 1024 row-form scan backward, the atomics-reduced parameter gradients) against the same step in
+    a process started with BEM_WGRAD_X6=0 BEM_SCAN_BWD_ROWS=0 (f32-MFMA weight gradients through LDS, generic scan backward): same loss,
+    and every parameter gradient within 1e-5 of the net's largest gradient element (the two forms differ by summation order only)."""
+    import subprocess
+    import sys
+    m = _cfg4()
+    loss, grads = m.compute(16, 256, 1)
+    out = tmp_path / "generic.pt"
+    env = dict(os.environ, BEM_WGRAD_X6="0", BEM_SCAN_BWD_ROWS="0")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(PKG), "scripts", "cfg4_grads.py"), str(out), "16", "256", "1"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    ref = torch.load(out, weights_only=True)
+    assert abs(loss - ref["loss"]) <= 2e-6 * abs(ref["loss"]), (loss, ref["loss"])
+    assert set(grads) == set(ref["grads"]) and len(grads) > 300
+    gmax = max(float(g.abs().max()) for g in ref["grads"].values())
+    worst = max((float((grads[k] - ref["grads"][k]).abs().max()), k) for k in grads)
+    assert worst[0] <= 1e-5 * gmax, (worst, gmax)
+    na = sum(float((g.double() ** 2).sum()) for g in grads.values()) ** 0.5
+    nb = sum(float((g.double() ** 2).sum()) for g in ref["grads"].values()) ** 0.5
+    assert abs(na - nb) <= 1e-5 * nb, (na, nb)
+
+
+def test_config4_full_width_batch_additivity_and_oracle_crop(dev):
+    """Size-independent checks of the full-width training step: (i) the L1-mean gradient of a 2-image batch at 256x256 equals the mean of
+    the two single-image gradients (every reduction over the batch -- weight gradients, scan parameter gradients, LayerNorm -- is linear in
+    the batch); (ii) one 64x64 pair through the SAME full-width net against oracle.train_step_ref (torch-CPU autograd of the restated net,
+    itself pinned by the reference fixture g10_train): loss, gradient norm and every gradient."""
+    from oracle import bem_oracle as O
+    m = _cfg4()
+    l2, g2 = m.compute(2, 256, 3)
+    la, ga = m.compute(2, 256, 3, images=slice(0, 1))
+    lb, gb = m.compute(2, 256, 3, images=slice(1, 2))
+    assert abs(l2 - 0.5 * (la + lb)) <= 2e-6 * l2
+    gmax = max(float(g.abs().max()) for g in g2.values())
+    worst = max((float((g2[k] - 0.5 * (ga[k] + gb[k])).abs().max()), k) for k in g2)
+    assert worst[0] <= 2e-5 * gmax, (worst, gmax)
+    # (ii) the oracle on one 64x64 pair of the same seeded full-width net
+    from basicsr.models import build_model
+    from basicsr.utils.options import parse
+    from bem import ops
+    from bem.pipeline import synthetic_pair
+    l1, g1 = m.compute(1, 64, 5)
+    opt = parse(os.path.join(PKG, "Options", "DecompDualBranch2DDWavelet_4.yml"), is_train=True)
+    opt["dist"] = False
+    torch.manual_seed(100)
+    sd = {k: v.detach().cpu() for k, v in build_model(opt).net_g.state_dict().items()}
+    lq, gt = synthetic_pair((1, 3, 64, 64), seed=5)
+    gd = ops.resize_down(gt.cuda(), 16).cpu()
+    ref = O.train_step_ref(sd, lq, gt, gd, steps=1, scan=O.selective_scan_ref)
+    assert abs(l1 - ref["loss"][0]) < 5e-6, (l1, ref["loss"][0])
+    n1 = sum(float((g.double() ** 2).sum()) for g in g1.values()) ** 0.5
+    assert abs(n1 - ref["grad_norm"][0]) <= 2e-3 * ref["grad_norm"][0], (n1, ref["grad_norm"][0])
+    rmax = max(float(g.abs().max()) for g in ref["grads"].values())
+    for k, g in ref["grads"].items():
+        assert float((g1[k] - g).abs().max()) <= 2e-3 * float(g.abs().max()) + 2e-5 * rmax, k
