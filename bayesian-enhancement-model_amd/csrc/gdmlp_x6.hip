@@ -58,25 +58,23 @@ __device__ __forceinline__ void glds16(const void* sbase, uint32_t voff, uint32_
 }
 __device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)p; }   // low half of a generic LDS pointer = LDS offset
 
-// GELU(a) * b for two pixels at once (erf by Abramowitz & Stegun 7.1.26 on the hardware rcp / exp2, as bem_gelu_fast)
-__device__ __forceinline__ f32x2 gelu_gate2(f32x2 a, f32x2 b) {
-    const float t0 = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, fabsf(a[0]), 1.f));
-    const float t1 = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, fabsf(a[1]), 1.f));
-    const f32x2 t = {t0, t1};
-    f32x2 p = __builtin_elementwise_fma(f32x2{1.061405429f, 1.061405429f}, t, f32x2{-1.453152027f, -1.453152027f});
-    p = __builtin_elementwise_fma(p, t, f32x2{1.421413741f, 1.421413741f});
-    p = __builtin_elementwise_fma(p, t, f32x2{-0.284496736f, -0.284496736f});
-    p = __builtin_elementwise_fma(p, t, f32x2{0.254829592f, 0.254829592f});
-    const f32x2 m = a * a * f32x2{-0.72134752044448170368f, -0.72134752044448170368f};       // -(a / sqrt 2)^2 log2 e
-    const f32x2 e = {__builtin_amdgcn_exp2f(m[0]), __builtin_amdgcn_exp2f(m[1])};
-    const f32x2 q = p * t;
-    const f32x2 r = __builtin_elementwise_fma(-q, e, f32x2{1.f, 1.f});                        // erf(|a| / sqrt 2)
-    const f32x2 s = {copysignf(r[0], a[0]), copysignf(r[1], a[1])};
-    const f32x2 h = a * f32x2{0.5f, 0.5f};
-    return __builtin_elementwise_fma(h, s, h) * b;
+// GELU(a) * b (erf by Abramowitz & Stegun 7.1.26 on the hardware rcp / exp2, as bem_gelu_fast).  Scalar f32 instructions on purpose:
+// on gfx950 a v_pk_*_f32 instruction does not overlap with another wave's MFMAs on the same SIMD, plain v_fma_f32 / v_exp_f32 do
+// (scripts/probes/coexec_probe.hip: 26 % of a packed stream hidden behind a matrix stream, 77 % of a scalar one, exp2 / rcp entirely) --
+// and both forms run at 64 FLOP per clock and SIMD, so nothing is lost by not packing.  This file is compiled with -fno-slp-vectorize.
+__device__ __forceinline__ float gelu_gate1(float a, float b) {
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, fabsf(a), 1.f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(a * a * -0.72134752044448170368f);           // exp(-(a / sqrt 2)^2)
+    const float r = fmaf(-(p * t), e, 1.f);                                              // erf(|a| / sqrt 2)
+    const float h = 0.5f * a;
+    return fmaf(h, copysignf(r, a), h) * b;
 }
 
-template <int KBM, int MTO, int WOB>
+template <int KBM, int MTO, int WOB, bool PL2>
 __global__ __launch_bounds__(256, 2) void gdmlp_x6_kernel(GdX k, const float* __restrict__ bpo, float bomul, float* __restrict__ out) {
     constexpr int NPI = 3 * KBM, NPO = 3 * MTO;                                        // 1 KiB pieces of a W_i / W_o chunk
     __shared__ __attribute__((aligned(16))) f32x2 T[16 * GD_TS];                       // [gate channel c][halo pixel] = (h1 input, h2 input)
@@ -120,6 +118,24 @@ __global__ __launch_bounds__(256, 2) void gdmlp_x6_kernel(GdX k, const float* __
     };
     dma_in(0, 0);
 
+    // phase-C geometry: wave = tile row, lane (n, kh) = pixel n, k-half kh
+    const int oy = y0 + wave, ox = x0 + n;
+    // residual + output bias of this wave's pixel row (rows (r & 3) + 8 (r >> 2) + 4 kh of each M-tile): requested
+    // ahead of the last phase C
+    f32x16 rs[MTO];
+    const bool opix = oy < k.H && ox < k.W;
+    const int64_t po = (int64_t)min(oy, k.H - 1) * k.W + min(ox, k.W - 1);
+    auto load_res = [&]() {
+        const float* rb = xb + po;
+#pragma unroll
+        for (int mt = 0; mt < MTO; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = min(32 * mt + (r & 3) + 8 * (r >> 2) + 4 * kh, k.C - 1);
+                rs[mt][r] = fmaf(bpo[row], bomul, rb[(int64_t)row * L]);
+            }
+    };
+
     // ---- this wave's halo pixel blocks (w, w + 4): load, LayerNorm over channels, zero outside the image, split into limbs
     u32x4 xl[2][KBM][3];
     float msk[2];
@@ -136,8 +152,10 @@ __global__ __launch_bounds__(256, 2) void gdmlp_x6_kernel(GdX k, const float* __
                 lnw[kb][e] = k.ln_w[min(ch, k.C - 1)] * on;
                 lnb[kb][e] = k.ln_b[min(ch, k.C - 1)] * on;
             }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        // PL2: every global load of the prologue is requested before the first value is used -- one exposed memory latency per workgroup,
+        // not one per halo block (C = 80 has no registers for that: 2 x 40 raw values next to 120 limb registers)
+        float xr[2][KBM][8];
+        auto load_block = [&](int i) {
             const int hp = min((wave + 4 * i) * 32 + n, GD_TS - 1);
             hpo[i] = hp;
             const int hy = hp / GD_HW, hx = hp - hy * GD_HW;
@@ -146,21 +164,22 @@ __global__ __launch_bounds__(256, 2) void gdmlp_x6_kernel(GdX k, const float* __
             msk[i] = in ? 1.f : 0.f;
             mbit[i] = in ? 0xffffffffu : 0u;
             const int off = min(max(gy, 0), k.H - 1) * k.W + min(max(gx, 0), k.W - 1);
-            float xr[KBM][8];
 #pragma unroll
             for (int kb = 0; kb < KBM; ++kb)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int ch = 16 * kb + 8 * kh + e;
                     const float v = xb[(int64_t)min(ch, k.C - 1) * L + off];
-                    xr[kb][e] = ch < k.C ? v : 0.f;
+                    xr[i][kb][e] = ch < k.C ? v : 0.f;
                 }
+        };
+        auto norm_block = [&](int i) {
             const float inv = 1.f / (float)k.C;
             float s = 0.f;
 #pragma unroll
             for (int kb = 0; kb < KBM; ++kb)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) s += xr[kb][e];
+                for (int e = 0; e < 8; ++e) s += xr[i][kb][e];
             s += __shfl_xor(s, 32, 64);
             const float mean = s * inv;
             float q = 0.f;
@@ -168,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void gdmlp_x6_kernel(GdX k, const float* __
             for (int kb = 0; kb < KBM; ++kb)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float d = (16 * kb + 8 * kh + e < k.C) ? xr[kb][e] - mean : 0.f;
+                    const float d = (16 * kb + 8 * kh + e < k.C) ? xr[i][kb][e] - mean : 0.f;
                     q = fmaf(d, d, q);
                 }
             q += __shfl_xor(q, 32, 64);
@@ -177,17 +196,17 @@ __global__ __launch_bounds__(256, 2) void gdmlp_x6_kernel(GdX k, const float* __
             for (int kb = 0; kb < KBM; ++kb) {
                 float v[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = ((xr[kb][e] - mean) * rstd) * lnw[kb][e] + lnb[kb][e] * msk[i];
+                for (int e = 0; e < 8; ++e) v[e] = ((xr[i][kb][e] - mean) * rstd) * lnw[kb][e] + lnb[kb][e] * msk[i];
                 split8(v, xl[i][kb][0], xl[i][kb][1], xl[i][kb][2]);
             }
-        }
+        };
+        if (PL2) { load_block(0); load_block(1); norm_block(0); norm_block(1); }
+        else { load_block(0); norm_block(0); load_block(1); norm_block(1); }
     }
 
     // phase-B geometry: lane = column n, tile rows 2 kh and 2 kh + 1; the window of both starts at halo (2 kh, n)
     const int wb_lds = 2 * kh * GD_HW + n;
     const int c_lo = 4 * wave;
-    // phase-C geometry: wave = tile row, lane (n, kh) = pixel n, k-half kh
-    const int oy = y0 + wave, ox = x0 + n;
 
     f32x16 oh[MTO];
 #pragma unroll
@@ -274,15 +293,16 @@ __global__ __launch_bounds__(256, 2) void gdmlp_x6_kernel(GdX k, const float* __
                 for (int dy = 0; dy < 4; ++dy)
 #pragma unroll
                     for (int dx = 0; dx < 3; ++dx) win[dy][dx] = tp[dy * GD_HW + dx];
-                f32x2 a0 = bias, a1 = bias;
+                float a0x = bias[0], a0y = bias[1], a1x = bias[0], a1y = bias[1];         // (h1, h2) of pixel rows 2kh and 2kh + 1
 #pragma unroll
                 for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
                     for (int tx = 0; tx < 3; ++tx) {
-                        a0 = __builtin_elementwise_fma(wq[3 * ty + tx], win[ty][tx], a0);
-                        a1 = __builtin_elementwise_fma(wq[3 * ty + tx], win[ty + 1][tx], a1);
+                        const f32x2 w = wq[3 * ty + tx], u0 = win[ty][tx], u1 = win[ty + 1][tx];
+                        a0x = fmaf(w[0], u0[0], a0x); a0y = fmaf(w[1], u0[1], a0y);
+                        a1x = fmaf(w[0], u1[0], a1x); a1y = fmaf(w[1], u1[1], a1y);
                     }
-                g[cc] = gelu_gate2(f32x2{a0[0], a1[0]}, f32x2{a0[1], a1[1]});
+                g[cc] = f32x2{gelu_gate1(a0x, a0y), gelu_gate1(a1x, a1y)};
             }
 #pragma unroll
             for (int p = 0; p < 2; ++p)
@@ -291,19 +311,18 @@ __global__ __launch_bounds__(256, 2) void gdmlp_x6_kernel(GdX k, const float* __
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    load_res();                                                                        // requested ahead of the last matrix phase
     phase_c(Wos[(k.NCH - 1) & (WOB - 1)]);
 
     // ---- epilogue: + bias + residual, rows (r & 3) + 8 (r >> 2) + 4 kh of each M-tile, 128-byte segments per half-wave
-    if (oy < k.H && ox < k.W) {
-        const int64_t po = (int64_t)oy * k.W + ox;
+    if (opix) {
         float* ob = out + (int64_t)b * k.C * L + po;
-        const float* rb = xb + po;
 #pragma unroll
         for (int mt = 0; mt < MTO; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (row < k.C) ob[(int64_t)row * L] = oh[mt][r] + bpo[row] * bomul + rb[(int64_t)row * L];
+                if (row < k.C) ob[(int64_t)row * L] = oh[mt][r] + rs[mt][r];
             }
     }
 }
@@ -333,10 +352,10 @@ extern "C" int bem_gdmlp_x6_f32(const float* x, const float* ln_w, const float* 
     hipStream_t s = (hipStream_t)stream;
     const int KB = cdiv(C, 16);
     // two workgroups per CU in every variant (LDS: T 26 KB + G 10 KB + two W_i buffers + one or two W_o buffers <= 80 KB)
-    if (KB == 1) gdmlp_x6_kernel<1, 1, 2><<<grid, 256, 0, s>>>(k, bpop, bomul, out);
-    else if (KB == 2) gdmlp_x6_kernel<2, 1, 2><<<grid, 256, 0, s>>>(k, bpop, bomul, out);
-    else if (KB == 3) gdmlp_x6_kernel<3, 2, 2><<<grid, 256, 0, s>>>(k, bpop, bomul, out);
-    else if (KB == 4) gdmlp_x6_kernel<4, 2, 2><<<grid, 256, 0, s>>>(k, bpop, bomul, out);
-    else gdmlp_x6_kernel<5, 3, 1><<<grid, 256, 0, s>>>(k, bpop, bomul, out);
+    if (KB == 1) gdmlp_x6_kernel<1, 1, 2, true><<<grid, 256, 0, s>>>(k, bpop, bomul, out);
+    else if (KB == 2) gdmlp_x6_kernel<2, 1, 2, true><<<grid, 256, 0, s>>>(k, bpop, bomul, out);
+    else if (KB == 3) gdmlp_x6_kernel<3, 2, 2, true><<<grid, 256, 0, s>>>(k, bpop, bomul, out);
+    else if (KB == 4) gdmlp_x6_kernel<4, 2, 2, true><<<grid, 256, 0, s>>>(k, bpop, bomul, out);
+    else gdmlp_x6_kernel<5, 3, 1, false><<<grid, 256, 0, s>>>(k, bpop, bomul, out);
     return bem_check_launch("gdmlp_x6");
 }

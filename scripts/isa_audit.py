@@ -48,7 +48,7 @@ ALLOW_SCRATCH = {
     r"ss2d_scan_rows_kernel<512, 2, 2, 5, 6, true, -1>": "L = 4096 combined form: 12 B; measured 145 us against 152 us for the best scratch-free split (profiles/r02)",
     r"ss2d_scan_rows_kernel<512, 2, [12], 5, [58], true, 1>|ss2d_scan_rows_kernel<1024, 1, 2, 5, 6, true, 1>": "L = 4096 split experiments (BEM_SCAN_SPLIT=2..4)",
     r"ss2d_scan_bwd_kernel<1024, 4>": "general-L fallback of the scan backward (ragged planes); the shipped plane sizes use ss2d_scan_bwd_rows_kernel",
-    r"gdmlp_x6_kernel<5, 3, 1>": "C = 80 form (x limbs of two halo blocks = 120 registers): three dwords parked across the chunk loop -- stored in the prologue, reloaded in the epilogue, no scratch access inside the loop (12 B)",
+    r"gdmlp_x6_kernel<5, 3, 1, false>": "C = 80 form (x limbs of two halo blocks = 120 registers): three dwords parked across the chunk loop -- stored in the prologue, reloaded in the epilogue, no scratch access inside the loop (12 B)",
     r"wgrad_kernel<3, 2":"checked separately: launch bound (256, 1) gives it 512 registers",
 }
 
