@@ -500,6 +500,9 @@ _CONV_PACK_X6 = {}       # same keys -> (9 taps, x6-packed (Cout, Cin)) weights 
 USE_CONV_X6 = __import__("os").environ.get("BEM_CONV_X6", "1") != "0"
 # the 16-tap form of the 4x4 stride-2 convolution measured no faster than the f32-MFMA im2col kernel (504 vs 537 us at 40 -> 80): off by default
 USE_CONV4_X6 = __import__("os").environ.get("BEM_CONV4_X6", "0") != "0"
+# 4x4 stride-2 down-sampling convs on the x6 matrix-core kernel with coalesced row loads and LDS-staged tap weights (conv4_x6.hip);
+# BEM_CONV4_FAST=0 restores the f32-MFMA im2col kernel
+CONV4_FAST = __import__("os").environ.get("BEM_CONV4_FAST", "1") != "0"
 
 
 def _packed_conv_weight_x6(w):
@@ -552,7 +555,10 @@ def conv2d(x, w, bias=None, stride=1, pad=1, relu=False, res1=None, res2=None, c
         check(lib().bem_conv3x3_x6_f32(xp, Ct * H * W, _p(_packed_conv_weight_x6(w)), _p(bias), _p(res1), _p(res2), _p(out), B, Cin, H, W,
                                        Cout, int(relu), _stream()), "conv3x3_x6")
         return out
-    if USE_CONV4_X6 and USE_X6 and (KH, KW, stride, pad) == (4, 4, 2, 1) and Wo % 2 == 0 and Cin % 8 == 0 and (c0 * H * W) % 2 == 0:
+    conv4_fast = CONV4_FAST and USE_X6 and (KH, KW, stride, pad) == (4, 4, 2, 1) and res1 is None and res2 is None and (c0 * H * W) % 4 == 0 \
+        and (Ct * H * W) % 4 == 0 and x.data_ptr() % 16 == 0 and lib().bem_conv4x4s2_fast_supported(Cin, H, W) == 1
+    if (conv4_fast or USE_CONV4_X6) and USE_X6 and (KH, KW, stride, pad) == (4, 4, 2, 1) and Wo % 2 == 0 and Cin % 8 == 0 and (c0 * H * W) % 2 == 0:
+        # conv4_fast: the coalesced-row form (conv4_x6.hip; power-of-two output widths <= 64); else the 16 shifted taps (BEM_CONV4_X6=1)
         check(lib().bem_conv4x4s2_x6_f32(xp, Ct * H * W, _p(_packed_conv_weight_x6(w)), _p(bias), _p(res1), _p(res2), _p(out), B, Cin, H, W,
                                          Cout, int(relu), _stream()), "conv4x4s2_x6")
         return out

@@ -48,16 +48,6 @@ constexpr int GD_GS = 20;                            // dwords per pixel row of 
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// one 1 KiB piece global -> LDS: lane l moves the 16 bytes at sbase + voff (voff = 16 l) to lds_dst + 16 l.  sbase is wave-uniform (an
-// SGPR pair: no per-lane 64-bit address arithmetic), M0 carries the wave-uniform LDS byte address.  Not visible to the compiler's
-// wait-count bookkeeping: the caller drains with s_waitcnt vmcnt(0) before the barrier that publishes the bytes.
-__device__ __forceinline__ void glds16(const void* sbase, uint32_t voff, uint32_t lds_dst) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)p; }   // low half of a generic LDS pointer = LDS offset
-
 // GELU(a) * b (erf by Abramowitz & Stegun 7.1.26 on the hardware rcp / exp2, as bem_gelu_fast).  Scalar f32 instructions on purpose:
 // on gfx950 a v_pk_*_f32 instruction does not overlap with another wave's MFMAs on the same SIMD, plain v_fma_f32 / v_exp_f32 do
 // (scripts/probes/coexec_probe.hip: 26 % of a packed stream hidden behind a matrix stream, 77 % of a scalar one, exp2 / rcp entirely) --

@@ -870,8 +870,16 @@ extern "C" int bem_conv3x3_x6_f32(const float* x, int64_t x_bstride, const float
     return conv_taps_launch(x, x_bstride, Wp, bias, res1, res2, out, B, Cin, H, W, Cout, 3, 1, 1, relu, stream, "conv3x3_x6");
 }
 
+extern "C" int bem_conv4x4s2_fast_supported(int Cin, int H, int W);
+int conv4s2_fast_launch(const float* x, int64_t x_bstride, const float* Wp, const float* bias, float* out, int B, int Cin, int H, int W, int Cout,
+                        int relu, void* stream);                                       // conv4_x6.hip
+
 extern "C" int bem_conv4x4s2_x6_f32(const float* x, int64_t x_bstride, const float* Wp, const float* bias, const float* res1,
                                     const float* res2, float* out, int B, int Cin, int H, int W, int Cout, int relu, void* stream) {
+    // the coalesced-row form (conv4_x6.hip) where the shape allows; the 16 shifted taps otherwise (residual inputs, other widths)
+    static const bool fast = !(getenv("BEM_CONV4_FAST") && atoi(getenv("BEM_CONV4_FAST")) == 0);
+    if (fast && !res1 && !res2 && Cin > 0 && bem_conv4x4s2_fast_supported(Cin, H, W) && ((uintptr_t)x & 15) == 0 && x_bstride % 4 == 0)
+        return conv4s2_fast_launch(x, x_bstride, Wp, bias, out, B, Cin, H, W, Cout, relu, stream);
     return conv_taps_launch(x, x_bstride, Wp, bias, res1, res2, out, B, Cin, H, W, Cout, 4, 2, 1, relu, stream, "conv4x4s2_x6");
 }
 

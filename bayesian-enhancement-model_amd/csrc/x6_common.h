@@ -64,4 +64,14 @@ __device__ __forceinline__ void mac6(const u32x4 (&w)[3], const u32x4 (&x)[3], f
     hi = mfma16(w[0], x[0], hi);
 }
 
+// one 1 KiB piece global -> LDS: lane l moves the 16 bytes at sbase + voff (voff = 16 l) to lds_dst + 16 l.  sbase is wave-uniform (an
+// SGPR pair: no per-lane 64-bit address arithmetic), M0 carries the wave-uniform LDS byte address.  Not visible to the compiler's
+// wait-count bookkeeping: the caller drains with s_waitcnt vmcnt(0) before the barrier that publishes the bytes.
+__device__ __forceinline__ void glds16(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)p; }   // low half of a generic LDS pointer = LDS offset
+
 }  // namespace

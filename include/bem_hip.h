@@ -184,7 +184,11 @@ int bem_conv2d_mfma_f32(const float* x, int64_t x_bstride, const float* Wp, cons
  * W even, Cin % 8 == 0; x_bstride as above; out = relu?(conv + bias) + res1 + res2. */
 int bem_conv3x3_x6_f32(const float* x, int64_t x_bstride, const float* Wp, const float* bias, const float* res1,
                        const float* res2, float* out, int B, int Cin, int H, int W, int Cout, int relu, void* stream);
-/* The 4x4 stride-2 pad-1 down-sampling convolution the same way (16 taps, tap = ky*4 + kx); even output width, Cin % 8 == 0. */
+/* The 4x4 stride-2 pad-1 down-sampling convolution (DecompDualBranchDDWavelet_arch.py:40-41) on the same machinery, tap = ky*4 + kx; even output
+ * width, Cin % 8 == 0.  Shapes bem_conv4x4s2_fast_supported accepts (W = 2 Wo with Wo a power of two <= 64, even H; x and x_bstride 16-byte
+ * aligned; no residual inputs) run the coalesced-row kernel of conv4_x6.hip: one aligned 16-byte load per lane, channel and input row, the two
+ * outer columns from the neighbour lanes, tap weights staged in LDS by LDS-DMA; other shapes run the 16 shifted taps. */
+int bem_conv4x4s2_fast_supported(int Cin, int H, int W);
 int bem_conv4x4s2_x6_f32(const float* x, int64_t x_bstride, const float* Wp, const float* bias, const float* res1,
                          const float* res2, float* out, int B, int Cin, int H, int W, int Cout, int relu, void* stream);
 

@@ -34,7 +34,7 @@ HIPCC = "/opt/rocm/bin/hipcc"
 ALLOW_SCRATCH = {
     r"conv2d_mfma_kernel<3, 3, 1": "f32-MFMA im2col 3x3: only with BEM_CONV_X6=0 / odd widths (default 3x3 path is conv_taps_x6_kernel)",
     r"conv2d_mfma_pipe_kernel<3, 3, 1, 1>": "3x3 with Cin % 8 != 0 and Cout <= 32 (Stage-I first_conv at 16x16): 36 B, launch-bound size",
-    r"conv2d_mfma_kernel<4, 4, 2": "4x4 stride-2 down-sampling: 1.4 % of the eval step; 16-tap x6 form measured no faster (DESIGN 6.6)",
+    r"conv2d_mfma_kernel<4, 4, 2": "f32-MFMA im2col 4x4 stride-2: only for shapes the coalesced-row x6 kernel (conv4_x6.hip) does not take (output widths that are not a power of two <= 64, e.g. config 5) or BEM_CONV4_FAST=0",
     r"attn_fold_kernel": "one 1024-thread workgroup per image folding 8 32x32 matrices: 8 B, ~40 us per step",
     r"pw_gemm3_reg_kernel|pw_gemm2_kernel|pw_gemm_kernel|pw_gemm3_stream_kernel": "f32-MFMA GEMMs: only with BEM_PW_X6=0",
     r"sample_pack_x6_kernel": "Stage-I weight sampling (Philox + Box-Muller + limb split per element, transcendental-bound): 48 B, 0.4 % of the step",

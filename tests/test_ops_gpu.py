@@ -776,3 +776,29 @@ def test_mc_mean(ops):
             pr = raw[b * N:(b + 1) * N, :, :h, :w].permute(0, 2, 3, 1).numpy()
             ref = O.mc_mean_ref(pr, tg[b].permute(1, 2, 0).numpy(), gm)
             close(got[b].permute(1, 2, 0), torch.from_numpy(ref), 2e-6, 2e-6, f"mc mean gt_mean={gm}")
+
+
+@pytest.mark.parametrize("cfg", [(2, 40, 80, 128, 128, False), (1, 80, 160, 64, 64, False), (2, 8, 7, 4, 4, False), (1, 24, 33, 6, 16, True),
+                                 (3, 16, 40, 2, 128, False), (1, 40, 96, 10, 32, True), (1, 48, 64, 34, 8, False)])
+def test_conv4x4s2_coalesced_rows(ops, cfg):
+    """The 4x4 stride-2 pad-1 down-sampling conv on the coalesced-row x6 kernel (conv4_x6.hip; DecompDualBranchDDWavelet_arch.py:40-41):
+    both bench shapes (40 -> 80 at 128x128, 80 -> 160 at 64x64), one / two / three row blocks of output channels incl. an odd count,
+    half-filled last k-block (Cin % 16 == 8), output rows of 2 .. 64 pixels (1 .. 32 lanes per row: every DPP neighbour / padding case),
+    odd output heights, a partly empty last wave, relu, a channel-slice input; against F.conv2d in float64 with the f32 run as yardstick."""
+    B, Ci, Co, H, W, relu = cfg
+    assert ops.CONV4_FAST and ops.lib().bem_conv4x4s2_fast_supported(Ci, H, W) == 1
+    g = torch.Generator().manual_seed(Ci + Co + H + W)
+    x, w, b = torch.randn(B, Ci, H, W, generator=g), torch.randn(Co, Ci, 4, 4, generator=g) * (Ci * 16) ** -0.5, torch.randn(Co, generator=g)
+
+    def run(dt):
+        y = F.conv2d(x.to(dt), w.to(dt), b.to(dt), stride=2, padding=1)
+        return F.relu(y) if relu else y
+    r64, r32 = run(torch.float64), run(torch.float32)
+    y = ops.conv2d(dev(x), dev(w), dev(b), stride=2, pad=1, relu=relu)
+    close(y, r32, 1e-4, 2e-5, f"conv4x4s2 {cfg}")
+    e32 = (r32.double() - r64).abs().mean().item()
+    e = (y.cpu().double() - r64).abs().mean().item()
+    assert e <= 1.5 * e32 + 1e-9, (e, e32)                   # the limb form's accuracy claim: not worse than torch's f32 convolution
+    if Ci >= 16:                                             # channels [8, 16) of the wider tensor
+        y2 = ops.conv2d(dev(x), dev(w[:, 8:16].contiguous()), None, stride=2, pad=1, cin_slice=(8, 8))
+        close(y2, F.conv2d(x[:, 8:16], w[:, 8:16], None, stride=2, padding=1), 1e-4, 2e-5, "conv4x4s2 channel slice")
