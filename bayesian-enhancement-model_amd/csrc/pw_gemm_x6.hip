@@ -865,21 +865,30 @@ static int conv_taps_launch(const float* x, int64_t x_bstride, const float* Wp, 
     return bem_check_launch(what);
 }
 
+extern "C" int bem_conv4x4s2_fast_supported(int Cin, int H, int W);
+extern "C" int bem_conv3x3_rows_supported(int Cin, int H, int W);
+int conv_rows_launch(int KS, const float* x, int64_t x_bstride, const float* Wp, const float* bias, const float* res1, const float* res2, float* out,
+                     int B, int Cin, int H, int W, int Cout, int relu, void* stream);                    // conv_rows_x6.hip
+static bool rows_aligned(const float* x, int64_t x_bstride, const float* out, const float* res1, const float* res2) {
+    return x && out && (((uintptr_t)x | (uintptr_t)out | (uintptr_t)(res1 ? res1 : out) | (uintptr_t)(res2 ? res2 : out)) & 15) == 0 && x_bstride % 4 == 0;
+}
+
 extern "C" int bem_conv3x3_x6_f32(const float* x, int64_t x_bstride, const float* Wp, const float* bias, const float* res1,
                                   const float* res2, float* out, int B, int Cin, int H, int W, int Cout, int relu, void* stream) {
+    // the row form (conv_rows_x6.hip) where the shape allows; nine shifted taps otherwise (BEM_CONV3_ROWS=0: always)
+    static const bool rows = !(getenv("BEM_CONV3_ROWS") && atoi(getenv("BEM_CONV3_ROWS")) == 0);
+    if (rows && Cin > 0 && bem_conv3x3_rows_supported(Cin, H, W) && rows_aligned(x, x_bstride, out, res1, res2))
+        return conv_rows_launch(3, x, x_bstride, Wp, bias, res1, res2, out, B, Cin, H, W, Cout, relu, stream);
     return conv_taps_launch(x, x_bstride, Wp, bias, res1, res2, out, B, Cin, H, W, Cout, 3, 1, 1, relu, stream, "conv3x3_x6");
 }
 
-extern "C" int bem_conv4x4s2_fast_supported(int Cin, int H, int W);
-int conv4s2_fast_launch(const float* x, int64_t x_bstride, const float* Wp, const float* bias, float* out, int B, int Cin, int H, int W, int Cout,
-                        int relu, void* stream);                                       // conv4_x6.hip
 
 extern "C" int bem_conv4x4s2_x6_f32(const float* x, int64_t x_bstride, const float* Wp, const float* bias, const float* res1,
                                     const float* res2, float* out, int B, int Cin, int H, int W, int Cout, int relu, void* stream) {
     // the coalesced-row form (conv4_x6.hip) where the shape allows; the 16 shifted taps otherwise (residual inputs, other widths)
     static const bool fast = !(getenv("BEM_CONV4_FAST") && atoi(getenv("BEM_CONV4_FAST")) == 0);
-    if (fast && !res1 && !res2 && Cin > 0 && bem_conv4x4s2_fast_supported(Cin, H, W) && ((uintptr_t)x & 15) == 0 && x_bstride % 4 == 0)
-        return conv4s2_fast_launch(x, x_bstride, Wp, bias, out, B, Cin, H, W, Cout, relu, stream);
+    if (fast && Cin > 0 && bem_conv4x4s2_fast_supported(Cin, H, W) && rows_aligned(x, x_bstride, out, res1, res2))
+        return conv_rows_launch(4, x, x_bstride, Wp, bias, res1, res2, out, B, Cin, H, W, Cout, relu, stream);
     return conv_taps_launch(x, x_bstride, Wp, bias, res1, res2, out, B, Cin, H, W, Cout, 4, 2, 1, relu, stream, "conv4x4s2_x6");
 }
 

@@ -189,6 +189,9 @@ int bem_conv3x3_x6_f32(const float* x, int64_t x_bstride, const float* Wp, const
  * aligned; no residual inputs) run the coalesced-row kernel of conv4_x6.hip: one aligned 16-byte load per lane, channel and input row, the two
  * outer columns from the neighbour lanes, tap weights staged in LDS by LDS-DMA; other shapes run the 16 shifted taps. */
 int bem_conv4x4s2_fast_supported(int Cin, int H, int W);
+/* 1 when bem_conv3x3_x6_f32 runs its row form (conv_rows_x6.hip: W a power of two in 4 .. 128, Cin % 8 == 0, 16-byte aligned tensors), the
+ * same kernel family with four output pixels per lane; other shapes run the nine shifted taps. */
+int bem_conv3x3_rows_supported(int Cin, int H, int W);
 int bem_conv4x4s2_x6_f32(const float* x, int64_t x_bstride, const float* Wp, const float* bias, const float* res1,
                          const float* res2, float* out, int B, int Cin, int H, int W, int Cout, int relu, void* stream);
 

@@ -802,3 +802,32 @@ def test_conv4x4s2_coalesced_rows(ops, cfg):
     if Ci >= 16:                                             # channels [8, 16) of the wider tensor
         y2 = ops.conv2d(dev(x), dev(w[:, 8:16].contiguous()), None, stride=2, pad=1, cin_slice=(8, 8))
         close(y2, F.conv2d(x[:, 8:16], w[:, 8:16], None, stride=2, padding=1), 1e-4, 2e-5, "conv4x4s2 channel slice")
+
+
+@pytest.mark.parametrize("cfg", [(2, 32, 32, 128, 128, True), (1, 32, 40, 128, 128, False), (2, 40, 16, 64, 64, True), (1, 8, 7, 5, 4, True),
+                                 (3, 24, 33, 3, 8, False), (1, 16, 80, 9, 32, True), (1, 48, 32, 1, 16, False), (1, 32, 32, 37, 128, True)])
+def test_conv3x3_row_form(ops, cfg):
+    """3x3 stride-1 pad-1 convs on the row-form x6 kernel (conv_rows_x6.hip; QD/model4.py:181-200, DecompDualBranchDDWavelet_arch.py:190):
+    the decomposition net's 32 -> 32 at 128x128, first_conv 32 -> 40 and proj 40 -> 16, rows of 4 .. 128 pixels (1 .. 32 lanes per row),
+    heights that leave the last wave partly empty, one / two / three row blocks of output channels, half-filled last k-block, relu and
+    both residual inputs, a channel-slice input; against F.conv2d in float64 with the f32 run as yardstick."""
+    B, Ci, Co, H, W, relu = cfg
+    assert ops.lib().bem_conv3x3_rows_supported(Ci, H, W) == 1
+    g = torch.Generator().manual_seed(Ci + Co + H + W)
+    x, w, b = torch.randn(B, Ci, H, W, generator=g), torch.randn(Co, Ci, 3, 3, generator=g) * (Ci * 9) ** -0.5, torch.randn(Co, generator=g)
+    r1, r2 = torch.randn(B, Co, H, W, generator=g), torch.randn(B, Co, H, W, generator=g)
+
+    def run(dt):
+        y = F.conv2d(x.to(dt), w.to(dt), b.to(dt), padding=1)
+        return (F.relu(y) if relu else y) + r1.to(dt) + r2.to(dt)
+    r64, r32 = run(torch.float64), run(torch.float32)
+    y = ops.conv2d(dev(x), dev(w), dev(b), stride=1, pad=1, relu=relu, res1=dev(r1), res2=dev(r2))
+    close(y, r32, 1e-4, 2e-5, f"conv3x3 rows {cfg}")
+    e32 = (r32.double() - r64).abs().mean().item()
+    e = (y.cpu().double() - r64).abs().mean().item()
+    assert e <= 1.5 * e32 + 1e-9, (e, e32)
+    y0 = ops.conv2d(dev(x), dev(w), None, stride=1, pad=1)                                  # no bias, no residuals
+    close(y0, F.conv2d(x, w, None, padding=1), 1e-4, 2e-5, "conv3x3 rows plain")
+    if Ci >= 16:
+        y2 = ops.conv2d(dev(x), dev(w[:, 8:16].contiguous()), None, stride=1, pad=1, cin_slice=(8, 8))
+        close(y2, F.conv2d(x[:, 8:16], w[:, 8:16], None, padding=1), 1e-4, 2e-5, "conv3x3 rows channel slice")
