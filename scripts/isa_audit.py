@@ -48,7 +48,7 @@ ALLOW_SCRATCH = {
     r"ss2d_scan_rows_kernel<512, 2, 2, 5, 6, true, -1>": "L = 4096 combined form: 12 B; measured 145 us against 152 us for the best scratch-free split (profiles/r02)",
     r"ss2d_scan_rows_kernel<512, 2, [12], 5, [58], true, 1>|ss2d_scan_rows_kernel<1024, 1, 2, 5, 6, true, 1>": "L = 4096 split experiments (BEM_SCAN_SPLIT=2..4)",
     r"ss2d_scan_bwd_kernel<1024, 4>": "general-L fallback of the scan backward (ragged planes); the shipped plane sizes use ss2d_scan_bwd_rows_kernel",
-    r"gdmlp_x6_kernel<5, 3, 1, false>": "C = 80 form (x limbs of two halo blocks = 120 registers): three dwords parked across the chunk loop -- stored in the prologue, reloaded in the epilogue, no scratch access inside the loop (12 B)",
+    r"gdmlp_x6_kernel<5, 3, 1, false>": "C = 80 form (x limbs of two halo blocks = 120 registers) at the 256-register budget of two workgroups per CU: 44 B",
     r"wgrad_kernel<3, 2":"checked separately: launch bound (256, 1) gives it 512 registers",
 }
 
@@ -61,9 +61,14 @@ PK = re.compile(r"^v_pk_(add|mul|fma)_f32\b")
 REG = re.compile(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b")
 
 
+# per-file compile flags of csrc/Makefile (the audit must look at the code that ships)
+EXTRA_FLAGS = {"gdmlp_x6.hip": ["-fno-slp-vectorize"]}
+
+
 def compile_to_isa(src):
     out = tempfile.mktemp(suffix=".s")
-    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-fast-math", "-S", "--cuda-device-only", "-o", out, src],
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-fast-math"] + EXTRA_FLAGS.get(os.path.basename(src), []) +
+                       ["-S", "--cuda-device-only", "-o", out, src],
                        cwd=CSRC, capture_output=True, text=True)
     if r.returncode:
         raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-2000:]}")

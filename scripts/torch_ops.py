@@ -1,9 +1,11 @@
-"""Which torch-side ops (copies, cats, ...) does one eval step still launch?"""
-import os, sys
+"""Which torch-side ops (copies, cats, fills ...) does one eval step still launch, and from where?
+   python scripts/torch_ops.py   -> table by op, then the Python call sites of every aten::copy_ / cat / fill / index op of one step."""
+import collections, os, sys, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "bayesian-enhancement-model_amd"))
 import torch
 from torch.profiler import profile, ProfilerActivity
+from torch.utils._python_dispatch import TorchDispatchMode
 from bem.pipeline import BEMPipeline, build_nets, synthetic_pair
 net1, net2 = build_nets(device="cuda")
 pipe = BEMPipeline(net1, net2)
@@ -15,3 +17,26 @@ with profile(activities=[ProfilerActivity.CPU], with_stack=False) as prof:
     pipe.enhance(lq, gt, 8, seed=5, sync=False)
     torch.cuda.synchronize()
 print(prof.key_averages().table(sort_by="count", row_limit=25, max_name_column_width=50))
+
+
+class Sites(TorchDispatchMode):
+    """every aten op that launches device work, keyed by the innermost frame inside this repo"""
+    def __init__(self):
+        super().__init__()
+        self.sites = collections.Counter()
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = str(func)
+        if not any(s in name for s in ("view", "reshape", "empty", "as_strided", "detach", "alias", "_unsafe_view", "expand", "permute", "transpose",
+                                       "select", "slice", "unsqueeze", "squeeze", "t.default", "size", "stride", "is_", "sym_", "_local_scalar")):
+            fr = [f for f in traceback.extract_stack() if "bayesian-enhancement-model_amd" in f.filename]
+            where = f"{os.path.basename(fr[-1].filename)}:{fr[-1].lineno}" if fr else "?"
+            self.sites[(name, where)] += 1
+        return func(*args, **(kwargs or {}))
+
+
+with Sites() as s:
+    pipe.enhance(lq, gt, 8, seed=6, sync=False)
+    torch.cuda.synchronize()
+for (name, where), c in s.sites.most_common(60):
+    print(f"{c:5d}  {name:40s} {where}")
