@@ -519,16 +519,25 @@ class SS2D(nn.Module):
         """x + out_proj(out_norm(merge(scan(SiLU(dw(in_proj(LN(x))))))))  (vmamba.py:700-716 + 547-698)."""
         B, C, H, W = x.shape
         Ci, R, L = self.d_inner, self.dt_rank, H * W
-        Wp, b = self.in_proj.gemm_weights(B)
-        t = ops.pw_gemm(x, Wp, Ci, ln=(norm.weight.detach(), norm.bias.detach()), ln_eps=norm.eps, bias=b)
-        w, b = self.conv2d.dw_weights(B)
-        xc = ops.dwconv3x3(t, w, b, mode=1)
         wall, dtw, dtb, A, Ds = self._scan_params()
+        front = SCAN_RM and ops.ss2d_scan_rm_supported(H, W, R) and ops.ss2d_front_supported(C, 4 * (R + 2)) and Ci == C \
+            and type(self.in_proj) is Linear2d and type(self.conv2d) is DwConv2d and ops.USE_X6
+        if front:
+            # LayerNorm + in_proj + depthwise 3x3 + SiLU + x_proj in one kernel (bem_ss2d_front_x6_f32): the in_proj output stays in LDS
+            Wpi, bi = self.in_proj.gemm_weights(B)
+            w, bw = self.conv2d.dw_weights(B)
+            xc, xd = ops.ss2d_front(x, norm.weight.detach(), norm.bias.detach(), norm.eps, Wpi, bi, w, bw, wall, 4 * (R + 2))
+        else:
+            Wp, b = self.in_proj.gemm_weights(B)
+            t = ops.pw_gemm(x, Wp, Ci, ln=(norm.weight.detach(), norm.bias.detach()), ln_eps=norm.eps, bias=b)
+            w, b = self.conv2d.dw_weights(B)
+            xc = ops.dwconv3x3(t, w, b, mode=1)
         Wp, b = self.out_proj.gemm_weights(B)
         on = self.out_norm
         if SCAN_RM and ops.ss2d_scan_rm_supported(H, W, R):
             # row-major scan: no transposed copy of xc, y1 comes back row-major (the column orientation goes through LDS)
-            xd = ops.pw_gemm(xc, wall, 4 * (R + 2))
+            if not front:
+                xd = ops.pw_gemm(xc, wall, 4 * (R + 2))
             xd1 = ops.transpose_plane_slice(xd, 2 * (R + 2), 2 * (R + 2))
             y0, y1 = ops.ss2d_scan_rm(xc, xd.view(B, 4, R + 2, L)[:, :2], xd1.view(B, 2, R + 2, L), dtw, dtb, A, Ds)
             return ops.pw_gemm(y0, Wp, _out_features(self.out_proj), x2=y1, in_mode=1,

@@ -92,6 +92,7 @@ SIGNATURES = {
     "bem_conv4x4s2_x6_f32": [P, I64, P, P, P, P, P, I, I, I, I, I, I, P],
     "bem_conv4x4s2_fast_supported": [I, I, I],
     "bem_conv3x3_rows_supported": [I, I, I],
+    "bem_ss2d_front_x6_f32": [P, P, P, F, P, P, P, P, P, P, P, I, I, I, I, I, P],
     "bem_conv_taps_x6_f32": [P, I64, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "bem_gdmlp_fused_f32": [ctypes.POINTER(GdmlpArgs), P],
     "bem_pack_pw_weight_gate_f32": [P, P, I, I, I, P],

@@ -353,6 +353,36 @@ def pi_gate(x, ln_w, ln_b, ln_eps, Wp_gate, bias_gate, dww, dwb, Hd):
     return g
 
 
+# SS2D front half (LayerNorm + in_proj + depthwise 3x3 + SiLU + x_proj) in one kernel for C <= 48, deterministic weights.  BEM_SS2D_FRONT=0
+# restores the three-kernel chain.
+SS2D_FRONT = os.environ.get("BEM_SS2D_FRONT", "1") != "0"
+
+
+def ss2d_front_supported(C, Mx):
+    return USE_X6 and SS2D_FRONT and C <= 48 and C % 8 == 0 and Mx <= 32
+
+
+def ss2d_front(x, ln_w, ln_b, ln_eps, Wp_in, bias_in, dww, dwb, Wp_x, Mx):
+    """xc = SiLU(dw3x3(in_proj(LayerNorm2d(x)))) (B,C,H,W) and xd = x_proj(xc) (B,Mx,H,W) in ONE kernel (bem_ss2d_front_x6_f32).
+    Wp_in = pack_pw_weight(W_in (C,C), x6=True), Wp_x = pack_pw_weight(W_x (Mx,C), x6=True); dww (C,1,3,3) or (C,9)."""
+    for n_, t in (("x", x), ("ln_w", ln_w), ("ln_b", ln_b), ("Wp_in", Wp_in), ("dww", dww), ("Wp_x", Wp_x)):
+        _chk(t, n_)
+    _chk(bias_in, "bias_in", optional=True); _chk(dwb, "dwb", optional=True)
+    B, C, H, W = x.shape
+    if not (USE_X6 and C <= 48 and C % 8 == 0 and Mx <= 32):
+        raise ValueError(f"ss2d_front: C = {C} (<= 48, % 8) / Mx = {Mx} (<= 32) not supported")
+    if ln_w.numel() != C or ln_b.numel() != C or dww.numel() != 9 * C or (dwb is not None and dwb.numel() != C) or (bias_in is not None and bias_in.numel() != C):
+        raise ValueError("ss2d_front: parameter shapes")
+    for Wp, (M, K), nm in ((Wp_in, (C, C), "Wp_in"), (Wp_x, (Mx, C), "Wp_x")):
+        if Wp.dim() != 2 or Wp.shape[0] != 1 or Wp.shape[1] != packed_elems(M, K, True) or getattr(Wp, "_bem_mk", (M, K)) != (M, K):
+            raise ValueError(f"ss2d_front: {nm} {tuple(Wp.shape)} does not match M={M} K={K} (x6 format, one weight set)")
+    xc = torch.empty_like(x)
+    xd = torch.empty(B, Mx, H, W, device=x.device, dtype=x.dtype)
+    check(lib().bem_ss2d_front_x6_f32(_p(x), _p(ln_w), _p(ln_b), float(ln_eps), _p(Wp_in), _p(bias_in), _p(dww), _p(dwb), _p(Wp_x), _p(xc), _p(xd),
+                                      B, C, Mx, H, W, _stream()), "ss2d_front")
+    return xc, xd
+
+
 def gate_interleave(Hd, device):
     """row permutation of a (2Hd, ...) project_in parameter into the gate-interleaved order of bem_gdmlp_x6_f32:
     new row 32 j + 2 c + s = old row s Hd + 16 j + c."""

@@ -656,7 +656,8 @@ extern "C" int bem_pw_gemm_x6_f32(const bem_pw_args* a, void* stream) {
     // one M-tile at a time where a wave holds two sub-tiles: the accumulator pairs double the register cost of an M-tile
     if (k.KB <= 3) BEM_X6_RES(3, 2, 1);
     if (ln && k.KB <= 5) BEM_X6_RES(5, 2, 1);
-    if (ln && k.KB <= 10) { if (k.MT == 1) BEM_X6_RES(10, 1, 1); else BEM_X6_RES(10, 1, 2); }
+    static const bool res10 = !(getenv("BEM_X6_RES10") && atoi(getenv("BEM_X6_RES10")) == 0);       // A/B: the two-sweep streaming form instead
+    if (ln && k.KB <= 10 && res10) { if (k.MT == 1) BEM_X6_RES(10, 1, 1); else BEM_X6_RES(10, 1, 2); }
 #undef BEM_X6_RES
     {
         // M-tiles per pass over x: every extra grid.y slice re-reads the input.  Two with 64-pixel waves; for exactly three

@@ -322,6 +322,15 @@ int bem_gdmlp_x6_f32(const float* x, const float* ln_w, const float* ln_b, float
                      const float* bias_gate, const float* dw_gate10, const float* Wp_out,
                      const float* bias_out, float* out, int B, int C, int Hd, int H, int W, void* stream);
 
+/* SS2D front half in one kernel (vmamba.py:700-716 up to the scan, with the block's norm :1326):
+ *   xc (B,C,H,W) = SiLU(dw3x3(W_in LayerNorm2d(x) + b_in) + b_dw),   xd (B,Mx,H*W) = W_x xc  (Mx = 4 (R + 2): the x_dbl rows of all four directions).
+ * The in_proj output exists only as a 4 x 32 pixel tile (+ halo) in LDS.  x (B,C,H,W) with C <= 48, C % 8 == 0, xc != x; ln_w / ln_b (C);
+ * Wp_in = bem_pack_pw_weight_x6 of the (C, C) in_proj matrix, bias_in (C) | NULL; dww (C,9), dwb (C) | NULL: depthwise 3x3;
+ * Wp_x = bem_pack_pw_weight_x6 of the (Mx, C) x_proj rows, Mx <= 32. */
+int bem_ss2d_front_x6_f32(const float* x, const float* ln_w, const float* ln_b, float ln_eps, const float* Wp_in, const float* bias_in,
+                          const float* dww, const float* dwb, const float* Wp_x, float* xc, float* xd, int B, int C, int Mx, int H, int W,
+                          void* stream);
+
 /* gdMlp front half (vmamba.py:116-131 up to the gate, with the block's norm2 :1330) in one kernel:
  *   g (B,Hd,H,W) = GELU(h[0:Hd]) * h[Hd:2Hd],  h = dw3x3(W_i * LayerNorm2d(x) + b_i) + dwb.
  * x (B,C,H,W) with C <= 80 (8 x 32 pixel tiles up to C = 48, 4 x 32 beyond); ln_w / ln_b (C); Wp_gate = bem_pack_pw_weight_x6 of the (2Hd, C) project_in matrix whose rows were

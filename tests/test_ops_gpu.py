@@ -831,3 +831,36 @@ def test_conv3x3_row_form(ops, cfg):
     if Ci >= 16:
         y2 = ops.conv2d(dev(x), dev(w[:, 8:16].contiguous()), None, stride=1, pad=1, cin_slice=(8, 8))
         close(y2, F.conv2d(x[:, 8:16], w[:, 8:16], None, padding=1), 1e-4, 2e-5, "conv3x3 rows channel slice")
+
+
+@pytest.mark.parametrize("cfg", [(2, 40, 3, 16, 64, True), (4, 40, 3, 128, 128, False), (2, 24, 2, 13, 45, True), (1, 8, 1, 8, 32, False),
+                                 (3, 48, 3, 5, 3, True), (1, 16, 6, 33, 70, True), (1, 32, 2, 4, 32, False)])
+def test_ss2d_front_x6_vs_chain_and_float64(ops, cfg):
+    """bem_ss2d_front_x6_f32 (LayerNorm + in_proj + depthwise 3x3 + SiLU + x_proj in one kernel, the in_proj output only in LDS) against the
+    three-kernel chain and against torch in float64 (vmamba.py:700-716,1326): image borders inside and across the 4 x 32 tiles, ragged planes,
+    C not a multiple of 16, with / without biases, the bench's level-0 shape."""
+    B, C, R, H, W, bias = cfg
+    Mx = 4 * (R + 2)
+    g = torch.Generator().manual_seed(C * Mx + H)
+    x = torch.randn(B, C, H, W, generator=g) * 2 + 0.3
+    lw, lb = 1 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    wi = torch.randn(C, C, generator=g) * C ** -0.5
+    bi = 0.3 * torch.randn(C, generator=g) if bias else None
+    wd = torch.randn(C, 1, 3, 3, generator=g) / 3
+    bd = 0.2 * torch.randn(C, generator=g) if bias else None
+    wx = torch.randn(Mx, C, generator=g) * C ** -0.5
+    Wpi, Wpx = ops.pack_pw_weight(dev(wi), x6=True), ops.pack_pw_weight(dev(wx), x6=True)
+    xg = dev(x)
+    xc, xd = ops.ss2d_front(xg, dev(lw), dev(lb), 1e-6, Wpi, None if bi is None else dev(bi), dev(wd), None if bd is None else dev(bd), Wpx, Mx)
+    t = ops.pw_gemm(xg, Wpi, C, ln=(dev(lw), dev(lb)), ln_eps=1e-6, bias=None if bi is None else dev(bi))
+    xc_ref = ops.dwconv3x3(t, dev(wd), None if bd is None else dev(bd), 1)
+    xd_ref = ops.pw_gemm(xc_ref, Wpx, Mx)
+    close(xc, xc_ref, 1e-4, 4e-5, f"ss2d_front xc vs chain {cfg}")
+    close(xd, xd_ref, 1e-4, 4e-5, f"ss2d_front xd vs chain {cfg}")
+    xd64 = x.double()
+    mu, var = xd64.mean(1, keepdim=True), xd64.var(1, unbiased=False, keepdim=True)
+    n = (xd64 - mu) / (var + 1e-6).sqrt() * lw.double()[None, :, None, None] + lb.double()[None, :, None, None]
+    tt = F.conv2d(n, wi.double()[:, :, None, None], None if bi is None else bi.double())
+    c64 = F.silu(F.conv2d(tt, wd.double(), None if bd is None else bd.double(), padding=1, groups=C))
+    close(xc, c64.float(), 1e-4, 4e-5, f"ss2d_front xc vs torch f64 {cfg}")
+    close(xd, F.conv2d(c64, wx.double()[:, :, None, None]).float(), 1e-4, 4e-5, f"ss2d_front xd vs torch f64 {cfg}")
