@@ -40,12 +40,7 @@ class _Cache:
         return val
 
 
-# dw3x3 + gate fused into the project_out loader (bem_gate_proj_x6_f32): correct (tests/test_ops_gpu.py) but VALU-bound at one
-# pixel per lane -- 189 vs 232 img/s end to end -- so off by default
-GATE_PROJ = __import__("os").environ.get("BEM_GATE_PROJ", "0") != "0"
 SCAN_RM = os.environ.get("BEM_SCAN_RM", "1") != "0"          # row-major SS2D scan (no transposes of xc / y1) where the plane size allows
-PI_GATE = os.environ.get("BEM_PI_GATE", "1") != "0"          # project_in + depthwise 3x3 + gate in one kernel where it applies (C <= ops.PI_GATE_MAXC = 48)
-FUSE_GDMLP = os.environ.get("BEM_FUSE_GDMLP", "0") != "0"    # 0: unfused three-kernel gdMlp (kept for A/B checks)
 
 
 def grad_mode(m: nn.Module) -> bool:
@@ -380,10 +375,6 @@ class Linear2dReparameterization(_BayesBase):
 # ------------------------------------------------------------------------------------------------
 # SS2D / gdMlp / VSSBlock  (basicsr/vmamba/models/vmamba.py:116-133, 438-716, 1241-1334)
 # ------------------------------------------------------------------------------------------------
-def _has_bias(m):
-    return (m.bias is not None) if isinstance(m, nn.Conv2d) else bool(m.bias)
-
-
 def _out_features(m):
     return m.out_features if hasattr(m, "out_features") else m.out_channels
 
@@ -399,32 +390,10 @@ class gdMlp(nn.Module):
         self.act = act_layer()
         self._cache = _Cache()
 
-    def _fused_params(self, B):
-        """(Wpi gate-packed, bpi, dww, dwb, Wpo packed, bpo) -- cached when deterministic, drawn per call when Bayesian."""
-        pi, dw, po = self.project_in, self.dwconv, self.project_out
-        Hd = pi.out_channels // 2
-        if isinstance(pi, PwConv2d):
-            def prep():
-                return (ops.pack_pw_weight_gate(pi.weight.detach().reshape(2 * Hd, -1).contiguous(), Hd), pi.bias.detach().contiguous(),
-                        dw.weight.detach().reshape(2 * Hd, 9).contiguous(), None if dw.bias is None else dw.bias.detach().contiguous(),
-                        ops.pack_pw_weight(po.weight.detach().reshape(po.out_channels, Hd).contiguous(), x6=False),
-                        None if po.bias is None else po.bias.detach().contiguous())
-            return self._cache.get("fused", [pi.weight, pi.bias, dw.weight, po.weight], prep)
-        w, b, ns = pi._sampled(B)
-        Wpi = ops.pack_pw_weight_gate(w.reshape(ns, 2 * Hd, -1).contiguous(), Hd)
-        w2, b2, _ = dw._sampled(B)
-        w3, b3, _ = po._sampled(B)
-        Wpo = ops.pack_pw_weight(w3.reshape(ns, po.out_channels, Hd).contiguous(), x6=False)
-        return Wpi, b.contiguous(), w2.reshape(ns, 2 * Hd * 9).contiguous(), (None if b2 is None else b2.contiguous()), Wpo, \
-            (None if b3 is None else b3.contiguous())
-
     def forward_fused(self, x, norm: LayerNorm2d):
         """x + project_out(GELU(h1) * h2), h = dwconv(project_in(LN(x)))."""
         B, C = x.shape[0], x.shape[1]
         Hd = self.project_in.out_channels // 2
-        if FUSE_GDMLP and ops.gdmlp_fused_supported(C, Hd) and _has_bias(self.project_in):
-            Wpi, bpi, dww, dwb, Wpo, bpo = self._fused_params(B)
-            return ops.gdmlp_fused(x, norm.weight.detach(), norm.bias.detach(), norm.eps, Wpi, bpi, dww, dwb, Wpo, bpo, Hd)
         if isinstance(self.project_in, PwConv2d) and isinstance(self.dwconv, DwConv2d) and isinstance(self.project_out, PwConv2d) \
                 and ops.gdmlp_x6_supported(C, Hd):
             # the whole branch in one kernel (bem_gdmlp_x6_f32): neither the 2Hd-channel nor the Hd-channel tensor reaches HBM
@@ -439,27 +408,7 @@ class gdMlp(nn.Module):
                         None if po.bias is None else po.bias.detach().contiguous())
             Wg, bg, w10, Wo, bo = self._cache.get("gdmlp_x6", [t for t in (pi.weight, pi.bias, dw.weight, dw.bias, po.weight, po.bias) if t is not None], prep)
             return ops.gdmlp_x6(x, norm.weight.detach(), norm.bias.detach(), norm.eps, Wg, bg, w10, Wo, bo, Hd)
-        if PI_GATE and isinstance(self.project_in, PwConv2d) and isinstance(self.dwconv, DwConv2d) and ops.pi_gate_supported(C, Hd):
-            # the 2Hd-channel project_in output lives only in LDS (bem_pi_gate_x6_f32); deterministic weights, C <= ops.PI_GATE_MAXC
-            pi, dw = self.project_in, self.dwconv
-
-            def prep():
-                perm = ops.gate_order(Hd, pi.weight.device)
-                return (ops.pack_pw_weight(pi.weight.detach().reshape(2 * Hd, C)[perm].contiguous(), x6=True),
-                        None if pi.bias is None else pi.bias.detach()[perm].contiguous()) + \
-                    ops.dw_gate_params(dw.weight.detach(), None if dw.bias is None else dw.bias.detach(), Hd)
-            Wg, bg, w, bw = self._cache.get("pi_gate", [t for t in (pi.weight, pi.bias, dw.weight, dw.bias) if t is not None], prep)
-            g = ops.pi_gate(x, norm.weight.detach(), norm.bias.detach(), norm.eps, Wg, bg, w, bw, Hd)
-            Wp, b = self.project_out.gemm_weights(B)
-            return ops.pw_gemm(g, Wp, _out_features(self.project_out), bias=b, res=x)
         Wp, b = self.project_in.gemm_weights(B)
-        if GATE_PROJ and ops.USE_X6:
-            # depthwise 3x3 + gate inside the loader of project_out: the gated Hd-channel tensor never exists in HBM
-            t = ops.empty_padded((B, 2 * Hd) + tuple(x.shape[2:]), x.device)
-            ops.pw_gemm(x, Wp, _out_features(self.project_in), ln=(norm.weight.detach(), norm.bias.detach()), ln_eps=norm.eps, bias=b, out=t)
-            w, bw = self.dwconv.dw_weights(B)
-            Wp, b = self.project_out.gemm_weights(B)
-            return ops.gate_proj(t, w, bw, Wp, _out_features(self.project_out), bias=b, res=x)
         t = ops.pw_gemm(x, Wp, _out_features(self.project_in), ln=(norm.weight.detach(), norm.bias.detach()),
                         ln_eps=norm.eps, bias=b)
         w, b = self.dwconv.dw_weights(B)

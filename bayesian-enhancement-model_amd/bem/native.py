@@ -31,17 +31,6 @@ class PwArgs(ctypes.Structure):
     ]
 
 
-class GdmlpArgs(ctypes.Structure):
-    """Mirror of ``bem_gdmlp_args`` (include/bem_hip.h)."""
-    _fields_ = [
-        ("x", c_void_p), ("out", c_void_p), ("ln_w", c_void_p), ("ln_b", c_void_p), ("ln_eps", c_float),
-        ("Wpi", c_void_p), ("wpi_bstride", c_int64), ("bpi", c_void_p), ("bpi_bstride", c_int64),
-        ("dww", c_void_p), ("dww_bstride", c_int64), ("dwb", c_void_p), ("dwb_bstride", c_int64),
-        ("Wpo", c_void_p), ("wpo_bstride", c_int64), ("bpo", c_void_p), ("bpo_bstride", c_int64),
-        ("B", c_int), ("C", c_int), ("Hd", c_int), ("H", c_int), ("W", c_int),
-    ]
-
-
 class WgradArgs(ctypes.Structure):
     """Mirror of ``bem_wgrad_args`` (include/bem_hip.h)."""
     _fields_ = [
@@ -68,14 +57,12 @@ SIGNATURES = {
     "bem_ss2d_scan_strided_f32": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I64, I64, P],
     "bem_ss2d_scan_rm_supported": [I, I, I],
     "bem_ss2d_scan_rm_f32": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I64, I64, P],
-    "bem_pw_gemm_f32": [ctypes.POINTER(PwArgs), P],
     "bem_pack_pw_weight_f32": [P, P, I, I, I, P],
     "bem_pw_packed_elems": [I, I],
     "bem_pw_gemm_x6_f32": [ctypes.POINTER(PwArgs), P],
     "bem_pack_pw_weight_x6": [P, P, I, I, I, P],
     "bem_pw_x6_packed_elems": [I, I],
     "bem_bnn_sample_pack_x6": [P, P, P, P, I, I, I, U64, U64, I, P],
-    "bem_gate_proj_x6_f32": [P, P, I64, P, I64, P, I64, P, I64, P, P, I, I, I, I, I, P],
     "bem_bnn_prior_ema_f32": [P, P, P, P, F, I64, P],
     "bem_bnn_kl_f32": [P, P, P, P, I64, P, P],
     "bem_bnn_kl_bwd_f32": [P, P, P, P, I64, P, P, P, P],
@@ -86,7 +73,6 @@ SIGNATURES = {
     "bem_prelu_f32": [P, P, P, I64, P],
     "bem_prelu_bwd_f32": [P, P, P, P, P, I64, P],
     "bem_bilinear_up_bwd_f32": [P, P, I, I, I, I, I, P],
-    "bem_pi_gate_x6_f32": [P, P, P, F, P, P, P, P, P, I, I, I, I, I, P],
     "bem_gdmlp_x6_f32": [P, P, P, F, P, P, P, P, P, P, I, I, I, I, I, P],
     "bem_conv3x3_x6_f32": [P, I64, P, P, P, P, P, I, I, I, I, I, I, P],
     "bem_conv4x4s2_x6_f32": [P, I64, P, P, P, P, P, I, I, I, I, I, I, P],
@@ -94,8 +80,6 @@ SIGNATURES = {
     "bem_conv3x3_rows_supported": [I, I, I],
     "bem_ss2d_front_x6_f32": [P, P, P, F, P, P, P, P, P, P, P, I, I, I, I, I, P],
     "bem_conv_taps_x6_f32": [P, I64, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P],
-    "bem_gdmlp_fused_f32": [ctypes.POINTER(GdmlpArgs), P],
-    "bem_pack_pw_weight_gate_f32": [P, P, I, I, I, P],
     "bem_dwconv3x3_f32": [P, P, I64, P, I64, P, I, I, I, I, I, P],
     "bem_conv2d_f32": [P, I64, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "bem_conv2d_mfma_f32": [P, I64, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P],

@@ -166,11 +166,10 @@ def transpose_plane_slice(x, c0, C):
 
 
 # --------------------------------------------------------------------------- pointwise GEMM ---
-# Two operand formats for the same GEMM contract: "f32" (v_mfma_f32_32x32x2_f32, bem_pw_gemm_f32) and "x6" (three bf16
-# limbs per f32 value, six limb products on v_mfma_f32_32x32x16_bf16, bem_pw_gemm_x6_f32 -- f32-level error at 6/16 of
-# the matrix-pipe cost).  pack_pw_weight picks the format, pw_gemm recognises it from the packed size (the two sizes
-# never coincide: 32 ceil(K/2) vs 768 ceil(K/16) floats per M-tile).  BEM_PW_X6=0 selects the f32 kernels everywhere.
-USE_X6 = __import__("os").environ.get("BEM_PW_X6", "1") != "0"
+# Two packed operand formats: "x6" (three bf16 limbs per f32 value, six limb products on v_mfma_f32_32x32x16_bf16, bem_pw_gemm_x6_f32 --
+# f32-level error at 6/16 of the f32 matrix-pipe cost), what every pointwise GEMM consumes; and "f32" (v_mfma_f32_32x32x2_f32 operand
+# order, pack_pw_weight(x6=False)), the weight format of the implicit-GEMM convolutions (bem_conv2d_mfma_f32).
+USE_X6 = True          # the pointwise GEMMs run on the bf16-limb kernels only (the f32-MFMA GEMMs were removed in round 3)
 # Bumped whenever parameters are rewritten behind torch's back (the fused optimizer step, bem.train.BemAdamW): every cache of
 # derived weights (packed / transposed / flipped copies) is keyed on it as well as on the tensors' data_ptr / _version.
 WEIGHT_EPOCH = [0]
@@ -223,11 +222,10 @@ def pw_gemm(x1, Wp, M, *, x2=None, in_mode=0, ln=None, ln_eps=1e-5, bias=None, r
     K = C1 + C2 if in_mode == 2 else C1
     if in_mode == 1 and C1 != C2:
         raise ValueError("pw_gemm sum mode: channel mismatch")
-    x6 = Wp.dim() == 2 and Wp.shape[1] == packed_elems(M, K, True)
     if getattr(Wp, "_bem_mk", (M, K)) != (M, K):
         raise ValueError(f"pw_gemm: weights packed for (M, K) = {Wp._bem_mk}, called with M={M} K={K}")
-    if Wp.dim() != 2 or not (x6 or Wp.shape[1] == packed_elems(M, K)) or Wp.shape[0] not in (1, B):
-        raise ValueError(f"pw_gemm: packed weight shape {tuple(Wp.shape)} does not match M={M} K={K} B={B}")
+    if Wp.dim() != 2 or Wp.shape[1] != packed_elems(M, K, True) or Wp.shape[0] not in (1, B):
+        raise ValueError(f"pw_gemm: packed weight shape {tuple(Wp.shape)} does not match M={M} K={K} B={B} (x6 format, pack_pw_weight)")
     a = PwArgs()
     a.x1, a.x2, a.C1, a.C2, a.in_mode = x1.data_ptr(), (x2.data_ptr() if x2 is not None else 0), C1, C2, in_mode
     if ln is not None:
@@ -263,7 +261,7 @@ def pw_gemm(x1, Wp, M, *, x2=None, in_mode=0, ln=None, ln_eps=1e-5, bias=None, r
         raise ValueError("pw_gemm: out shape")
     a.out = out.data_ptr()
     a.B, a.M, a.K, a.L = B, M, K, L
-    check((lib().bem_pw_gemm_x6_f32 if x6 else lib().bem_pw_gemm_f32)(ctypes.byref(a), _stream()), "pw_gemm")
+    check(lib().bem_pw_gemm_x6_f32(ctypes.byref(a), _stream()), "pw_gemm")
     return out
 
 
@@ -275,82 +273,6 @@ def empty_padded(shape, device, pad=4):
         n *= s_
     buf = torch.empty(n + 2 * pad, device=device, dtype=torch.float32)
     return buf[pad:pad + n].view(shape)
-
-
-def gate_proj(h, dww, dwb, Wp, M, bias=None, res=None):
-    """res + W_o * (GELU(dw3x3(h)[:Hd]) * dw3x3(h)[Hd:]) + bias in one kernel (bem_gate_proj_x6_f32).
-    h (B,2Hd,H,W) from ``empty_padded``; dww (2Hd,1,3,3) or (B,2Hd,1,3,3); dwb (2Hd) | (B,2Hd) | None; Wp x6-packed (1|B, ...)."""
-    _chk(h, "h"); _chk(dww, "dww"); _chk(dwb, "dwb", optional=True); _chk(Wp, "Wp"); _chk(bias, "bias", optional=True); _chk(res, "res", optional=True)
-    B, C2, H, W = h.shape
-    Hd = C2 // 2
-    st = h.untyped_storage()
-    if C2 % 2 or h.storage_offset() < 1 or st.nbytes() < 4 * (h.storage_offset() + h.numel() + 1):
-        raise ValueError("gate_proj: h must have an even channel count and one readable element before / after it (ops.empty_padded)")
-    per_b = dww.dim() == 5
-    if tuple(dww.shape[-4:]) != (C2, 1, 3, 3) or (per_b and dww.shape[0] != B):
-        raise ValueError(f"gate_proj: depthwise weight {tuple(dww.shape)} vs {C2} channels")
-    bb = 0
-    if dwb is not None:
-        if dwb.shape[-1] != C2 or (dwb.dim() == 2 and dwb.shape[0] not in (1, B)):
-            raise ValueError("gate_proj: depthwise bias shape")
-        bb = C2 if (dwb.dim() == 2 and dwb.shape[0] == B and B > 1) else 0
-    if Wp.dim() != 2 or Wp.shape[1] != packed_elems(M, Hd, True) or Wp.shape[0] not in (1, B) or getattr(Wp, "_bem_mk", (M, Hd)) != (M, Hd):
-        raise ValueError(f"gate_proj: packed weight {tuple(Wp.shape)} does not match M={M} K={Hd} (x6 format)")
-    ob = 0
-    if bias is not None:
-        if bias.shape[-1] != M or (bias.dim() == 2 and bias.shape[0] not in (1, B)):
-            raise ValueError("gate_proj: bias shape")
-        ob = M if (bias.dim() == 2 and bias.shape[0] > 1) else 0
-    if res is not None and tuple(res.shape) != (B, M, H, W):
-        raise ValueError("gate_proj: residual shape")
-    out = torch.empty(B, M, H, W, device=h.device, dtype=h.dtype)
-    check(lib().bem_gate_proj_x6_f32(_p(h), _p(dww), (C2 * 9 if per_b else 0), _p(dwb), bb, _p(Wp), (Wp.shape[1] if Wp.shape[0] > 1 else 0),
-                                     _p(bias), ob, _p(res), _p(out), B, Hd, M, H, W, _stream()), "gate_proj")
-    return out
-
-
-def gate_order(Hd, device):
-    """row permutation of a (2Hd, ...) project_in parameter into the gate order of bem_pi_gate_x6_f32."""
-    j = torch.arange(Hd // 16, device=device)[:, None]
-    r = torch.arange(16, device=device)[None, :]
-    return torch.cat([16 * j + r, Hd + 16 * j + r], 1).reshape(-1)
-
-
-# widest input the fused gdMlp front half is used for.  The kernel takes C <= 80, but its 8-wave / 4-row form for C > 48 (one workgroup
-# per CU) measured 503 us against 146 + 145 us for the two-kernel chain at the bench's level 1 (C = 80, 64 x 64 planes): default 48
-PI_GATE_MAXC = int(os.environ.get("BEM_PI_GATE_MAXC", "48"))
-
-
-def pi_gate_supported(C, Hd):
-    return USE_X6 and C <= PI_GATE_MAXC and Hd % 16 == 0
-
-
-def dw_gate_params(dww, dwb, Hd):
-    """depthwise (2Hd,1,3,3) / (2Hd) parameters -> the (Hd,9,2) / (Hd,2) per-gate-channel interleave of bem_pi_gate_x6_f32."""
-    w = dww.reshape(2, Hd, 9).permute(1, 2, 0).contiguous()
-    return w, (None if dwb is None else dwb.reshape(2, Hd).t().contiguous())
-
-
-def pi_gate(x, ln_w, ln_b, ln_eps, Wp_gate, bias_gate, dww, dwb, Hd):
-    """GELU(h1) * h2 with [h1; h2] = dw3x3(project_in(LayerNorm2d(x))) in one kernel (bem_pi_gate_x6_f32).
-    Wp_gate = pack_pw_weight(W_i[gate_order(Hd)], x6=True), bias_gate = b_i[gate_order(Hd)]; dww, dwb = dw_gate_params(...)."""
-    _chk(x, "x"); _chk(ln_w, "ln_w"); _chk(ln_b, "ln_b"); _chk(Wp_gate, "Wp_gate"); _chk(bias_gate, "bias_gate", optional=True)
-    _chk(dww, "dww"); _chk(dwb, "dwb", optional=True)
-    B, C, H, W = x.shape
-    if not pi_gate_supported(C, Hd):
-        raise ValueError(f"pi_gate: C = {C} (<= {PI_GATE_MAXC}) / Hd = {Hd} (% 16) not supported")
-    if tuple(dww.shape) != (Hd, 9, 2) or (dwb is not None and tuple(dwb.shape) != (Hd, 2)):
-        raise ValueError("pi_gate: depthwise parameters must come from dw_gate_params")
-    if ln_w.numel() != C or ln_b.numel() != C or dww.numel() != 2 * Hd * 9 or (dwb is not None and dwb.numel() != 2 * Hd) \
-            or (bias_gate is not None and bias_gate.numel() != 2 * Hd):
-        raise ValueError("pi_gate: parameter shapes")
-    if Wp_gate.dim() != 2 or Wp_gate.shape[0] != 1 or Wp_gate.shape[1] != packed_elems(2 * Hd, C, True) \
-            or getattr(Wp_gate, "_bem_mk", (2 * Hd, C)) != (2 * Hd, C):
-        raise ValueError(f"pi_gate: packed weight {tuple(Wp_gate.shape)} does not match M={2 * Hd} K={C} (x6 format, one weight set)")
-    g = torch.empty(B, Hd, H, W, device=x.device, dtype=x.dtype)
-    check(lib().bem_pi_gate_x6_f32(_p(x), _p(ln_w), _p(ln_b), float(ln_eps), _p(Wp_gate), _p(bias_gate), _p(dww), _p(dwb), _p(g),
-                                   B, C, Hd, H, W, _stream()), "pi_gate")
-    return g
 
 
 # SS2D front half (LayerNorm + in_proj + depthwise 3x3 + SiLU + x_proj) in one kernel for C <= 48, deterministic weights.  BEM_SS2D_FRONT=0
@@ -434,60 +356,6 @@ def gdmlp_x6(x, ln_w, ln_b, ln_eps, Wp_gate, bias_gate, dw10, Wp_out, bias_out, 
     return out
 
 
-def pack_pw_weight_gate(W, Hd):
-    """project_in weight (2Hd,K) or (nsets,2Hd,K) -> packed with gate rows regrouped per 16 channels."""
-    _chk(W, "W")
-    if W.dim() == 2:
-        W = W[None]
-    ns, M, K = W.shape
-    if M != 2 * Hd or Hd % 16:
-        raise ValueError("pack_pw_weight_gate: expects (2*Hd, K) with Hd % 16 == 0")
-    out = torch.empty(ns, (Hd // 16) * ((K + 1) // 2) * 64, device=W.device, dtype=W.dtype)
-    check(lib().bem_pack_pw_weight_gate_f32(_p(W), _p(out), ns, Hd, K, _stream()), "pack_pw_weight_gate")
-    return out
-
-
-def gdmlp_fused_supported(C, Hd):
-    return C <= 160 and Hd % 16 == 0
-
-
-def gdmlp_fused(x, ln_w, ln_b, ln_eps, Wpi, bpi, dww, dwb, Wpo, bpo, Hd):
-    """x (B,C,H,W) -> x + project_out(GELU(dw(h1)) * dw(h2)), h = project_in(LN(x)); see bem_gdmlp_fused_f32."""
-    for n, t in (("x", x), ("ln_w", ln_w), ("ln_b", ln_b), ("Wpi", Wpi), ("bpi", bpi), ("dww", dww), ("Wpo", Wpo)):
-        _chk(t, n)
-    _chk(dwb, "dwb", optional=True); _chk(bpo, "bpo", optional=True)
-    B, C, H, W = x.shape
-    KS = (C + 1) // 2
-
-    def bs(t, per):     # (tensor with optional leading batch dim) -> element stride between sets
-        if t is None:
-            return 0
-        n = t.numel()
-        if n == per:
-            return 0
-        if n == B * per:
-            return per
-        raise ValueError(f"gdmlp_fused: parameter of {n} elements matches neither {per} nor {B}x{per}")
-    a = native.GdmlpArgs()
-    a.x, a.ln_w, a.ln_b, a.ln_eps = x.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), ln_eps
-    if ln_w.numel() != C or ln_b.numel() != C:
-        raise ValueError("gdmlp_fused: LayerNorm size")
-    a.Wpi, a.wpi_bstride = Wpi.data_ptr(), bs(Wpi, (Hd // 16) * KS * 64)
-    a.bpi, a.bpi_bstride = bpi.data_ptr(), bs(bpi, 2 * Hd)
-    a.dww, a.dww_bstride = dww.data_ptr(), bs(dww, 2 * Hd * 9)
-    a.dwb, a.dwb_bstride = (dwb.data_ptr() if dwb is not None else 0), bs(dwb, 2 * Hd)
-    a.Wpo, a.wpo_bstride = Wpo.data_ptr(), bs(Wpo, packed_elems(C, Hd))
-    a.bpo, a.bpo_bstride = (bpo.data_ptr() if bpo is not None else 0), bs(bpo, C)
-    out = torch.empty_like(x)
-    a.out = out.data_ptr()
-    a.B, a.C, a.Hd, a.H, a.W = B, C, Hd, H, W
-    s = _timed("gdmlp_fused", 8.0 * x.numel(), 2.0 * B * H * W * (2 * Hd * C + Hd * C + 2 * Hd * 9)) if _PROF is not None else None
-    check(lib().bem_gdmlp_fused_f32(ctypes.byref(a), _stream()), "gdmlp_fused")
-    _timed_end(s)
-    return out
-
-
-# --------------------------------------------------------------------------- convolutions -----
 def dwconv3x3(x, w, bias=None, mode=0):
     """mode 0 plain, 1 SiLU, 2 gdMlp gate (x has 2*Cout channels), 3 PostSmooth.  w (Cw,1,3,3) or (B,Cw,1,3,3)."""
     _chk(x, "x"); _chk(w, "w"); _chk(bias, "bias", optional=True)
@@ -529,7 +397,6 @@ def _packed_conv_weight(w):
 _CONV_PACK_X6 = {}       # same keys -> (9 taps, x6-packed (Cout, Cin)) weights for the shifted-tap 3x3 convolution
 USE_CONV_X6 = __import__("os").environ.get("BEM_CONV_X6", "1") != "0"
 # the 16-tap form of the 4x4 stride-2 convolution measured no faster than the f32-MFMA im2col kernel (504 vs 537 us at 40 -> 80): off by default
-USE_CONV4_X6 = __import__("os").environ.get("BEM_CONV4_X6", "0") != "0"
 # 4x4 stride-2 down-sampling convs on the x6 matrix-core kernel with coalesced row loads and LDS-staged tap weights (conv4_x6.hip);
 # BEM_CONV4_FAST=0 restores the f32-MFMA im2col kernel
 CONV4_FAST = __import__("os").environ.get("BEM_CONV4_FAST", "1") != "0"
@@ -587,8 +454,8 @@ def conv2d(x, w, bias=None, stride=1, pad=1, relu=False, res1=None, res2=None, c
         return out
     conv4_fast = CONV4_FAST and USE_X6 and (KH, KW, stride, pad) == (4, 4, 2, 1) and res1 is None and res2 is None and (c0 * H * W) % 4 == 0 \
         and (Ct * H * W) % 4 == 0 and x.data_ptr() % 16 == 0 and lib().bem_conv4x4s2_fast_supported(Cin, H, W) == 1
-    if (conv4_fast or USE_CONV4_X6) and USE_X6 and (KH, KW, stride, pad) == (4, 4, 2, 1) and Wo % 2 == 0 and Cin % 8 == 0 and (c0 * H * W) % 2 == 0:
-        # conv4_fast: the coalesced-row form (conv4_x6.hip; power-of-two output widths <= 64); else the 16 shifted taps (BEM_CONV4_X6=1)
+    if conv4_fast:
+        # the coalesced-row form (conv_rows_x6.hip; power-of-two output widths <= 64); other shapes: the f32-MFMA implicit GEMM below
         check(lib().bem_conv4x4s2_x6_f32(xp, Ct * H * W, _p(_packed_conv_weight_x6(w)), _p(bias), _p(res1), _p(res2), _p(out), B, Cin, H, W,
                                          Cout, int(relu), _stream()), "conv4x4s2_x6")
         return out
@@ -665,7 +532,7 @@ def hamilton_full(q1, q2):
 
 
 def attn_fold(f1, f2, attn_w, fuse_w, fuse_b):
-    """Channel cross attention + fuse conv folded into per-image (32x64) weights: returns (Wp (B,2048), bias (B,32))."""
+    """Channel cross attention + fuse conv folded into per-image (32x64) weights: returns (Wp (B, x6-packed(32,64)), bias (B,32))."""
     for n, t in (("f1", f1), ("f2", f2), ("attn_w", attn_w), ("fuse_w", fuse_w), ("fuse_b", fuse_b)):
         _chk(t, n)
     B, C, H, W = f1.shape
@@ -674,10 +541,10 @@ def attn_fold(f1, f2, attn_w, fuse_w, fuse_b):
     L = H * W
     stats = torch.empty(B, 32 * 32 + 64, device=f1.device, dtype=torch.float64)
     check(lib().bem_attn_stats_f64(_p(f1), _p(f2), _p(stats), B, L, _stream()), "attn_stats")
-    Wp = torch.empty(B, 32 * 64, device=f1.device, dtype=torch.float32)
+    Wn = torch.empty(B, 32, 64, device=f1.device, dtype=torch.float32)
     bias = torch.empty(B, 32, device=f1.device, dtype=torch.float32)
-    check(lib().bem_attn_fold_f32(_p(stats), _p(attn_w), _p(fuse_w), _p(fuse_b), _p(Wp), _p(bias), B, L, _stream()), "attn_fold")
-    return Wp, bias
+    check(lib().bem_attn_fold_f32(_p(stats), _p(attn_w), _p(fuse_w), _p(fuse_b), _p(Wn), _p(bias), B, L, _stream()), "attn_fold")
+    return pack_pw_weight(Wn, x6=True), bias
 
 
 # --------------------------------------------------------------------------- layout helpers ---
@@ -1232,16 +1099,13 @@ _KEYS = {
     # the kernel with the largest share of the step in profiles/r01_bench_kernel_stats.csv
     "pw_x6_stream<2>": ("pw_gemm", "hbm", "pw_x6_stream_kernel<2, 2, false, true, false>",
                         lambda K, M, ln, L, mode: USE_X6 and K > 48 and not ln and M > 32 and L % 2 == 0 and mode != 1),
-    # the same role in the f32-MFMA build (BEM_PW_X6=0)
-    "pw_gemm3_reg<20,2>": ("pw_gemm", "hbm", "pw_gemm3_reg_kernel<20, 2, true, false>", lambda K, M, ln, L, mode: K <= 40 and M > 32 and L % 4 == 0 and mode != 1),
     "pw_gemm": ("pw_gemm", "mfma", "pw_gemm* (all variants)", lambda K, M, ln, L, mode: True),
-    "gdmlp_fused": ("gdmlp_fused", "mfma", "gdmlp_fused_kernel", None),
     # the whole gdMlp branch in one kernel: x in, out out -- 8 bytes per element of x are its algorithmic bytes
     # (HBM: 42 us at level 0) -- but its two GEMMs (2Hd x C and C x Hd per pixel) evaluated as six bf16 limb products are 242 GFLOP on the
     # matrix cores (97 us at the dense bf16 peak): the matrix pipe is the roofline that bounds it.  flops = 6 x the f32 GEMM flops
     # (what the x6 scheme must issue for the output pixels; halo and padding MFMAs are waste, not work).
-    "gdmlp_x6<3>": ("gdmlp_x6", "mfma_bf16", "gdmlp_x6_kernel<3, 2, 2>", lambda C: 32 < C <= 48),
-    "gdmlp_x6<5>": ("gdmlp_x6", "mfma_bf16", "gdmlp_x6_kernel<5, 3, 1>", lambda C: 64 < C <= 80),
+    "gdmlp_x6<3>": ("gdmlp_x6", "mfma_bf16", "gdmlp_x6_kernel<3, 2, 2, false>", lambda C: 32 < C <= 48),
+    "gdmlp_x6<5>": ("gdmlp_x6", "mfma_bf16", "gdmlp_x6_kernel<5, 3, 1, false>", lambda C: 64 < C <= 80),
     "conv2d": ("conv2d", "mfma", "conv2d_kernel", None),
     "dwconv3x3": ("dwconv3x3", "hbm", "dwconv3x3_kernel", None),
     "ss2d_scan": ("ss2d_scan", "hbm", "ss2d_scan_kernel", None),

@@ -291,15 +291,10 @@ __global__ __launch_bounds__(1024) void attn_fold_kernel(const double* __restric
     __syncthreads();
     const double left = X[i][j] + mm(Y, M2, i, j);
     const double right = mm(X, M1, i, j) + Y[i][j];
-    // packed layout for bem_pw_gemm (M = 32 -> one M-tile, K = 64 -> KS = 32):
-    //   Wp[st*64 + lane] = W[lane & 31][2*st + (lane >> 5)]
+    // natural (32, 64) row-major per image: columns 0..31 act on F1, 32..63 on F2 (the host packs it for the x6 GEMM)
     float* wp = Wp + (int64_t)b * (32 * 64);
-    {
-        int col = j;            // column of F1 block
-        wp[(col >> 1) * 64 + (col & 1) * 32 + i] = (float)left;
-        col = 32 + j;           // column of F2 block
-        wp[(col >> 1) * 64 + (col & 1) * 32 + i] = (float)right;
-    }
+    wp[i * 64 + j] = (float)left;
+    wp[i * 64 + 32 + j] = (float)right;
     if (j == 0) {
         double s = (double)fb[i];
         for (int k = 0; k < ATT_C; ++k) s += X[i][k] * c1[k] + Y[i][k] * c2[k];

@@ -176,7 +176,10 @@ __device__ __forceinline__ void x6_epilogue_rows(const PwX& k, int b, int mt0, i
 #endif
             const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
 #else
-            const float bv[4] = {bq[m][g].x, bq[m][g].y, bq[m][g].z, bq[m][g].w};
+            // through a VALU copy: a packed add that takes the HIGH register of a freshly loaded pair for its LOW result read the pair's
+            // pre-load content in lanes 48..63 (round 3: the M = 32, K = 64 attention-fuse GEMM at 280 workgroups, scripts/dbg_gemm_cat.py;
+            // round 2 saw the same with LDS-loaded pairs) -- DESIGN.md section 6.4, scripts/isa_audit.py check 2
+            const float bv[4] = {valu_copy(bq[m][g].x), valu_copy(bq[m][g].y), valu_copy(bq[m][g].z), valu_copy(bq[m][g].w)};
 #endif
             float rv[4][NSUB];
             if (RES) {
@@ -838,8 +841,8 @@ static int conv_taps_launch(const float* x, int64_t x_bstride, const float* Wp, 
                             float* out, int B, int Cin, int H, int W, int Cout, int KH, int stride, int dil, int relu, void* stream, const char* what) {
     BEM_REQUIRE(x && Wp && out, "%s: null tensor", what);
     BEM_REQUIRE(B >= 0 && B <= 65535 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "%s: bad shape", what);
-    BEM_REQUIRE((KH == 3 && stride == 1 && (dil == 1 || dil == 2)) || (KH == 3 && stride == 2 && dil == 1) || (KH == 4 && stride == 2 && dil == 1),
-                "%s: supported forms are 3x3 s1 (dilation 1 / 2, padding = dilation), 3x3 s2 p1 and 4x4 s2 p1", what);
+    BEM_REQUIRE((KH == 3 && stride == 1 && (dil == 1 || dil == 2)) || (KH == 3 && stride == 2 && dil == 1),
+                "%s: supported forms are 3x3 s1 (dilation 1 / 2, padding = dilation) and 3x3 s2 p1", what);
     const int pad = dil;                                        // "same" padding of the dilated 3x3; 1 for the others
     const int Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
     BEM_REQUIRE(Ho > 0 && Wo > 0 && Wo % 2 == 0 && Cin % 8 == 0 && H * W >= 2, "%s: needs an even output width and Cin %% 8 == 0 (got Wo=%d Cin=%d)", what, Wo, Cin);
@@ -856,12 +859,9 @@ static int conv_taps_launch(const float* x, int64_t x_bstride, const float* Wp, 
     if (KH == 3 && stride == 1) {
         if (mtw == 1) conv_taps_x6_kernel<1, 3, 3, 1><<<grid, 256, 0, s>>>(k);
         else conv_taps_x6_kernel<2, 3, 3, 1><<<grid, 256, 0, s>>>(k);
-    } else if (KH == 3) {
+    } else {
         if (mtw == 1) conv_taps_x6_kernel<1, 3, 3, 2><<<grid, 256, 0, s>>>(k);
         else conv_taps_x6_kernel<2, 3, 3, 2><<<grid, 256, 0, s>>>(k);
-    } else {
-        if (mtw == 1) conv_taps_x6_kernel<1, 4, 4, 2><<<grid, 256, 0, s>>>(k);
-        else conv_taps_x6_kernel<2, 4, 4, 2><<<grid, 256, 0, s>>>(k);
     }
     return bem_check_launch(what);
 }
@@ -886,181 +886,13 @@ extern "C" int bem_conv3x3_x6_f32(const float* x, int64_t x_bstride, const float
 
 extern "C" int bem_conv4x4s2_x6_f32(const float* x, int64_t x_bstride, const float* Wp, const float* bias, const float* res1,
                                     const float* res2, float* out, int B, int Cin, int H, int W, int Cout, int relu, void* stream) {
-    // the coalesced-row form (conv4_x6.hip) where the shape allows; the 16 shifted taps otherwise (residual inputs, other widths)
-    static const bool fast = !(getenv("BEM_CONV4_FAST") && atoi(getenv("BEM_CONV4_FAST")) == 0);
-    if (fast && Cin > 0 && bem_conv4x4s2_fast_supported(Cin, H, W) && rows_aligned(x, x_bstride, out, res1, res2))
-        return conv_rows_launch(4, x, x_bstride, Wp, bias, res1, res2, out, B, Cin, H, W, Cout, relu, stream);
-    return conv_taps_launch(x, x_bstride, Wp, bias, res1, res2, out, B, Cin, H, W, Cout, 4, 2, 1, relu, stream, "conv4x4s2_x6");
+    // the row form (conv_rows_x6.hip); shapes outside it (bem_conv4x4s2_fast_supported == 0) belong to bem_conv2d_mfma_f32
+    BEM_REQUIRE(Cin > 0 && bem_conv4x4s2_fast_supported(Cin, H, W) && rows_aligned(x, x_bstride, out, res1, res2),
+                "conv4x4s2_x6: needs W = 2 Wo with Wo a power of two <= 64, even H, Cin %% 8 == 0 and 16-byte aligned tensors");
+    return conv_rows_launch(4, x, x_bstride, Wp, bias, res1, res2, out, B, Cin, H, W, Cout, relu, stream);
 }
 
 extern "C" int bem_conv_taps_x6_f32(const float* x, int64_t x_bstride, const float* Wp, const float* bias, const float* res1, const float* res2,
                                     float* out, int B, int Cin, int H, int W, int Cout, int K, int stride, int dilation, int relu, void* stream) {
     return conv_taps_launch(x, x_bstride, Wp, bias, res1, res2, out, B, Cin, H, W, Cout, K, stride, dilation, relu, stream, "conv_taps_x6");
-}
-
-// ================================================================================================
-// gdMlp tail in one kernel:  out = x + W_o * ( GELU(dw3x3(h)[0:Hd]) * dw3x3(h)[Hd:2Hd] ) + b_o      (vmamba.py:124-133)
-// The depthwise 3x3 + gate runs in the loader of the project_out GEMM: the gated tensor (Hd channels) is never written or
-// re-read.  A wave owns 32 consecutive pixels (one per lane and half-wave); per gate channel it reads the 3x3
-// neighbourhoods of the a- and b-planes of h straight from global memory (row addresses clamped into the plane, rows and
-// columns outside the image masked -- h must be readable one element before / after every plane, see bem_gate_proj_x6_f32),
-// forms the gate value, and after 8 channels splits them into limbs and issues the limb products of one k-block against
-// W_o.  Depthwise weights and bias of this batch row are staged in LDS.  Loads of the next channel are requested before
-// the arithmetic of the current one.
-// ================================================================================================
-namespace {
-
-struct GpX {
-    const float* h; int Hd;
-    const float* dww; int64_t dww_bs; const float* dwb; int64_t dwb_bs;
-    const u32x4* Wp; int64_t w_bstride; const float* bias; int64_t bias_bstride;
-    const float* res; float* out;
-    int M, H, W, KB, MT;
-};
-
-struct f3 { float a, b, c; };
-
-template <int MTW>
-__global__ __launch_bounds__(256, 2) void gate_proj_x6_kernel(GpX k) {
-    extern __shared__ float gsm[];                          // dw weights [2 Hd][9] then dw bias [2 Hd]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kh = lane >> 5, n = lane & 31;
-    const int b = blockIdx.z, mt0 = blockIdx.y * MTW;
-    const int L = k.H * k.W, C2 = 2 * k.Hd;
-    float* s_w = gsm;
-    float* s_b = gsm + C2 * 9;
-    {
-        const float* wsrc = k.dww + (int64_t)b * k.dww_bs;
-        for (int i = threadIdx.x; i < C2 * 9; i += 256) s_w[i] = wsrc[i];
-        const float* bsrc = k.dwb ? k.dwb + (int64_t)b * k.dwb_bs : nullptr;
-        for (int i = threadIdx.x; i < C2; i += 256) s_b[i] = bsrc ? bsrc[i] : 0.f;
-    }
-    __syncthreads();                                        // the only barrier, before any early exit
-    const int p0 = (xcd_tile(blockIdx.x, gridDim.x) * 4 + wave) * 32;
-    if (p0 >= L) return;
-    const int p = p0 + n;
-    const bool live = p < L;
-    const int pc = live ? p : 0;
-    const int y = pc / k.W, x = pc - y * k.W;
-    int roff[3];
-    float mrow[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        const int yy = y + d - 1;
-        roff[d] = min(max(yy, 0), k.H - 1) * k.W + x - 1;   // first of the three pixels x-1, x, x+1 (may be one before / after the plane)
-        mrow[d] = (live && yy >= 0 && yy < k.H) ? 1.f : 0.f;
-    }
-    const float ml = x > 0 ? 1.f : 0.f, mr = x + 1 < k.W ? 1.f : 0.f;
-    const float* hb = k.h + (int64_t)b * C2 * L;
-    f32x16 acc[MTW], alo[MTW];
-#pragma unroll
-    for (int m = 0; m < MTW; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] = alo[m][r] = 0.f;
-    const u32x4* wbase = k.Wp + (int64_t)b * k.w_bstride + lane;
-    const int64_t mt_stride = (int64_t)k.KB * 3 * 64;
-    auto load_w = [&](int kb, u32x4 (&dst)[MTW][3]) {
-#pragma unroll
-        for (int m = 0; m < MTW; ++m) {
-            const bool ok = kb < k.KB && mt0 + m < k.MT;
-            const u32x4* wp = wbase + (int64_t)(mt0 + m < k.MT ? mt0 + m : 0) * mt_stride + (int64_t)min(kb, k.KB - 1) * 3 * 64;
-            const uint32_t mk = ok ? 0xffffffffu : 0u;
-#pragma unroll
-            for (int li = 0; li < 3; ++li) {
-                const u32x4 w = wp[li * 64];
-                dst[m][li] = u32x4{w[0] & mk, w[1] & mk, w[2] & mk, w[3] & mk};
-            }
-        }
-    };
-    // channel step i = 8 kb + e: this lane's gate channel 16 kb + 8 kh + e (clamped for the address; weights are zero beyond Hd)
-    auto chan = [&](int i) { return min(16 * (i >> 3) + 8 * kh + (i & 7), k.Hd - 1); };
-    auto load_c = [&](int i, f3 (&dst)[2][3]) {
-        const int c = chan(i);
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-            const float* base = hb + (int64_t)(c + pl * k.Hd) * L;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) __builtin_memcpy(&dst[pl][d], base + roff[d], sizeof(f3));   // 12-byte load, dword aligned
-        }
-    };
-    const int nch = k.KB * 8;
-    f3 cur[2][3], nxt[2][3];
-    u32x4 wn[MTW][3];
-    load_c(0, cur);
-    load_w(0, wn);
-    float g[8];
-    for (int i = 0; i < nch; ++i) {
-        load_c(min(i + 1, nch - 1), nxt);
-        const int c = chan(i);
-        float s[2];
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-            const float* kw = s_w + (c + pl * k.Hd) * 9;
-            float t = s_b[c + pl * k.Hd];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const float r = fmaf(kw[3 * d], cur[pl][d].a * ml, fmaf(kw[3 * d + 1], cur[pl][d].b, kw[3 * d + 2] * (cur[pl][d].c * mr)));
-                t = fmaf(mrow[d], r, t);
-            }
-            s[pl] = t;
-        }
-        g[i & 7] = bem_gelu_fast(s[0]) * s[1];
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-            for (int d = 0; d < 3; ++d) cur[pl][d] = nxt[pl][d];
-        if ((i & 7) == 7) {
-            const int kb = i >> 3;
-            u32x4 xl[3], wc[MTW][3];
-            split8(g, xl[0], xl[1], xl[2]);
-#pragma unroll
-            for (int m = 0; m < MTW; ++m)
-#pragma unroll
-                for (int li = 0; li < 3; ++li) wc[m][li] = wn[m][li];
-            load_w(kb + 1, wn);
-#pragma unroll
-            for (int m = 0; m < MTW; ++m) mac6(wc[m], xl, acc[m], alo[m]);
-        }
-    }
-    // epilogue: out = acc + bias + res   (one pixel per lane)
-    const float* gb = k.bias ? k.bias + (int64_t)b * k.bias_bstride : nullptr;
-    const uint32_t loff = (uint32_t)(4 * kh) * (uint32_t)L + (uint32_t)pc;
-    float* outb = k.out + (int64_t)b * k.M * L;
-    const float* resb = k.res ? k.res + (int64_t)b * k.M * L : nullptr;
-#pragma unroll
-    for (int m = 0; m < MTW; ++m) {
-        if (mt0 + m >= k.MT) continue;
-        const int rb = (mt0 + m) * 32;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int urow = rb + (r & 3) + 8 * (r >> 2);
-            const int lrow = min(urow + 4 * kh, k.M - 1);
-            float o = acc[m][r] + alo[m][r] + (gb ? gb[lrow] : 0.f);
-            if (resb) o += resb[(int64_t)lrow * L + pc];
-            if (live && urow + 4 * kh < k.M) outb[(int64_t)urow * L + loff] = o;
-        }
-    }
-}
-
-}  // namespace
-
-extern "C" int bem_gate_proj_x6_f32(const float* h, const float* dww, int64_t dww_bstride, const float* dwb, int64_t dwb_bstride,
-                                    const float* Wp, int64_t w_bstride, const float* bias, int64_t bias_bstride, const float* res,
-                                    float* out, int B, int Hd, int M, int H, int W, void* stream) {
-    BEM_REQUIRE(h && dww && Wp && out, "gate_proj_x6: null tensor");
-    BEM_REQUIRE(B >= 0 && B <= 65535 && Hd > 0 && M > 0 && M <= 64 * 32 && H > 0 && W > 0, "gate_proj_x6: bad shape");
-    BEM_REQUIRE(((uintptr_t)Wp & 15) == 0 && w_bstride % 4 == 0, "gate_proj_x6: packed weights must be 16-byte aligned");
-    BEM_REQUIRE((int64_t)M * H * W < (1ll << 30) && (int64_t)2 * Hd * H * W < (1ll << 31), "gate_proj_x6: plane set too large for 32-bit offsets");
-    const size_t lds = (size_t)2 * Hd * 10 * sizeof(float);
-    BEM_REQUIRE(lds <= 64 * 1024, "gate_proj_x6: 2*Hd = %d depthwise filters do not fit the LDS staging", 2 * Hd);
-    if (B == 0) return BEM_OK;
-    GpX k;
-    k.h = h; k.Hd = Hd; k.dww = dww; k.dww_bs = dww_bstride; k.dwb = dwb; k.dwb_bs = dwb_bstride;
-    k.Wp = reinterpret_cast<const u32x4*>(Wp); k.w_bstride = w_bstride / 4; k.bias = bias; k.bias_bstride = bias_bstride;
-    k.res = res; k.out = out; k.M = M; k.H = H; k.W = W; k.KB = cdiv(Hd, 16); k.MT = cdiv(M, 32);
-    const int mtw = k.MT == 1 ? 1 : 2;
-    dim3 grid(cdiv(H * W, 128), cdiv(k.MT, mtw), B);
-    hipStream_t s = (hipStream_t)stream;
-    if (mtw == 1) gate_proj_x6_kernel<1><<<grid, 256, lds, s>>>(k);
-    else gate_proj_x6_kernel<2><<<grid, 256, lds, s>>>(k);
-    return bem_check_launch("gate_proj_x6");
 }

@@ -92,13 +92,13 @@ int bem_ss2d_scan_rm_f32(const float* x, const float* xd0, const float* xd1, con
                          int64_t xd0_bstride, int64_t xd1_bstride, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Pointwise (1x1) channel-mix GEMM on f32 MFMA with fused prologue / epilogue.  Replaces
+ * Pointwise (1x1) channel-mix GEMM with fused prologue / epilogue (argument block of bem_pw_gemm_x6_f32).  Replaces
  * Linear2d / nn.Conv2d(k=1) / LayerNorm2d+Linear2d chains (vmamba.py:42-63,123-133,702,715,1326-1334).
  *
  *   out[b][m][p] = act( sum_k W[b?][m][k] * pro(x)[b][k][p] + bias[b?][m] ) + res[b][m][p]
  *   pro: in_mode 0: x = x1 (K = C1) | 1: x = x1 + x2 (K = C1 = C2) | 2: x = cat(x1, x2) (K = C1 + C2);
  *        then LayerNorm over the K channels of each pixel when ln_w != NULL (eps = ln_eps).
- *   Wp : weights pre-packed by bem_pack_pw_weight_f32; w_bstride / bias_bstride = element stride
+ *   Wp : weights pre-packed by bem_pack_pw_weight_x6; w_bstride / bias_bstride = element stride
  *        between per-batch-element weight sets (0 = shared by the whole batch).
  *   act: 0 none, 1 PReLU with the single slope *prelu.
  *   out_mode 0: out (B,M,L).  out_mode 1: ConvTranspose2d(k=2,s=2) scatter -- M = 4*Co, row
@@ -114,9 +114,8 @@ typedef struct {
     float* out; int out_mode; int Win;
     int B; int M; int K; int L;
 } bem_pw_args;
-int bem_pw_gemm_f32(const bem_pw_args* a, void* stream);
-/* natural (nsets, M, K) row-major -> packed MFMA operand order (nsets, MT, KS, 64), MT = ceil(M/32),
- * KS = ceil(K/2); returns the packed element count per set through *packed_elems when non-NULL. */
+/* natural (nsets, M, K) row-major -> packed f32-MFMA operand order (nsets, MT, KS, 64), MT = ceil(M/32), KS = ceil(K/2):
+ * the weight format of the implicit-GEMM convolutions (bem_conv2d_mfma_f32). */
 int bem_pack_pw_weight_f32(const float* W, float* Wp, int nsets, int M, int K, void* stream);
 int64_t bem_pw_packed_elems(int M, int K);
 
@@ -134,25 +133,6 @@ int64_t bem_pw_x6_packed_elems(int M, int K);
  * sampler's Philox draws for (seed, stream_id) -- identical values to sampling first and packing afterwards. */
 int bem_bnn_sample_pack_x6(const float* mu, const float* rho, const float* eps, float* Wp, int nsets, int M, int K,
                            uint64_t seed, uint64_t stream_id, int sigma_given, void* stream);   /* sigma_given: rho already holds log1p(exp(rho)) */
-
-/* ---------------------------------------------------------------------------------------------
- * Fused gdMlp block (vmamba.py:116-133 + the norm2 / residual around it, vmamba.py:1330-1333):
- *   out = x + Wo * (GELU(dw3x3(h)[0:Hd]) * dw3x3(h)[Hd:2Hd]) + bo,  h = Wi * LayerNorm_C(x) + bi
- * x, out (B,C,H,W), C <= 160, Hd % 16 == 0, out != x.  Wpi: Wi (2Hd,C) packed by
- * bem_pack_pw_weight_gate_f32 (gate rows regrouped per 16 channels); Wpo: Wo (C,Hd) packed by
- * bem_pack_pw_weight_f32; dww (2Hd,9), dwb (2Hd) or NULL, bpi (2Hd), bpo (C) or NULL natural.
- * *_bstride: elements between per-batch-element parameter sets (0 = shared).
- * ------------------------------------------------------------------------------------------- */
-typedef struct {
-    const float* x; float* out;
-    const float* ln_w; const float* ln_b; float ln_eps;
-    const float* Wpi; int64_t wpi_bstride; const float* bpi; int64_t bpi_bstride;
-    const float* dww; int64_t dww_bstride; const float* dwb; int64_t dwb_bstride;
-    const float* Wpo; int64_t wpo_bstride; const float* bpo; int64_t bpo_bstride;
-    int B; int C; int Hd; int H; int W;
-} bem_gdmlp_args;
-int bem_gdmlp_fused_f32(const bem_gdmlp_args* a, void* stream);
-int bem_pack_pw_weight_gate_f32(const float* W, float* Wp, int nsets, int Hd, int K, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Convolutions.
@@ -221,11 +201,12 @@ int bem_hamilton_full_f32(const float* q1, const float* q2, float* out, int B, i
 /* Channel cross-attention of the decomposition net (QD/model4.py:81-139) folded with the 1x1 `fuse`
  * conv that follows it.  Step 1: accumulate per image S = F1 F2^T (32x32), s1 = F1 1, s2 = F2 1 in f64
  * (stats: (B, 32*32 + 64) doubles, zeroed by the call).  Step 2: softmax + fold all 1x1 weights into
- * one per-image (32 x 64) matrix + bias (written pre-packed for bem_pw_gemm_f32 in_mode 2). */
+ * one per-image (32 x 64) matrix + bias: W_out (B, 32, 64) row-major, columns 0..31 for f1, 32..63 for f2 (bem_pw_gemm_x6_f32 in_mode 2
+ * after bem_pack_pw_weight_x6). */
 int bem_attn_stats_f64(const float* f1, const float* f2, double* stats, int B, int L, void* stream);
 int bem_attn_fold_f32(const double* stats, const float* attn_w /* 8 x (32x32 + 32): q1,k2,v2,q2,k1,v1,out1,out2 */,
                       const float* fuse_w /* (32,64) */, const float* fuse_b /* (32) */,
-                      float* Wp_out /* (B, packed(32,64)) */, float* bias_out /* (B,32) */, int B, int L,
+                      float* W_out /* (B, 32, 64) */, float* bias_out /* (B,32) */, int B, int L,
                       void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -299,16 +280,6 @@ int bem_select_scores_f32(const float* cand, const float* s1, const float* s2, f
 int bem_mc_mean_f32(const float* pred, const float* target, float* out, double* ws, int B, int N, int Hp, int Wp, int h, int w,
                     int gt_mean, void* stream);
 
-/* gdMlp tail (vmamba.py:124-133) in one kernel: out = res + W_o * ( GELU(dw3x3(h)[0:Hd]) * dw3x3(h)[Hd:2Hd] ) + bias.
- * h (B,2Hd,H,W) = project_in output; it must be readable ONE ELEMENT BEFORE ITS FIRST AND AFTER ITS LAST element (the 3x3
- * window of a plane's first / last pixel is fetched unclamped and masked) -- allocate it inside a larger buffer.
- * dww (2Hd,9) / dwb (2Hd)|NULL depthwise parameters, *_bstride elements between per-batch-row sets (0 = shared);
- * Wp = bem_pack_pw_weight_x6 of W_o (M,Hd), w_bstride / bias_bstride as in bem_pw_args; res (B,M,H,W) or NULL.
- * The gated tensor is never written: the depthwise conv + gate run in the loader of the x6 GEMM. */
-int bem_gate_proj_x6_f32(const float* h, const float* dww, int64_t dww_bstride, const float* dwb, int64_t dwb_bstride,
-                         const float* Wp, int64_t w_bstride, const float* bias, int64_t bias_bstride, const float* res,
-                         float* out, int B, int Hd, int M, int H, int W, void* stream);
-
 /* The whole gdMlp branch of a VSSBlock in one kernel (vmamba.py:116-133 gdMlp.forward + the block's norm2 / residual :1330-1333):
  *   out (B,C,H,W) = x + W_o (GELU(h[0:Hd]) * h[Hd:2Hd]) + b_o,   h = dw3x3(W_i LayerNorm2d(x) + b_i) + b_dw.
  * Neither the 2Hd-channel project_in output nor the Hd-channel gate tensor reaches HBM (4 x 32 pixel tiles, both live as 16-gate-channel
@@ -330,17 +301,6 @@ int bem_gdmlp_x6_f32(const float* x, const float* ln_w, const float* ln_b, float
 int bem_ss2d_front_x6_f32(const float* x, const float* ln_w, const float* ln_b, float ln_eps, const float* Wp_in, const float* bias_in,
                           const float* dww, const float* dwb, const float* Wp_x, float* xc, float* xd, int B, int C, int Mx, int H, int W,
                           void* stream);
-
-/* gdMlp front half (vmamba.py:116-131 up to the gate, with the block's norm2 :1330) in one kernel:
- *   g (B,Hd,H,W) = GELU(h[0:Hd]) * h[Hd:2Hd],  h = dw3x3(W_i * LayerNorm2d(x) + b_i) + dwb.
- * x (B,C,H,W) with C <= 80 (8 x 32 pixel tiles up to C = 48, 4 x 32 beyond); ln_w / ln_b (C); Wp_gate = bem_pack_pw_weight_x6 of the (2Hd, C) project_in matrix whose rows were
- * regrouped per 16 gate channels: packed row 32 j + r = W_i[16 j + r] for r < 16, W_i[Hd + 16 j + r - 16] for r >= 16
- * (Hd % 16 == 0); bias_gate (2Hd, same row order, 16-byte aligned) | NULL; depthwise parameters interleaved per gate channel:
- * dw_gate (Hd,9,2, 16-byte aligned): [c][tap] = (dww[c][tap], dww[Hd + c][tap]); dwb_gate (Hd,2) = (dwb[c], dwb[Hd + c]) | NULL.
- * The 2Hd-channel project_in output only exists as 32-row slices of one pixel tile in LDS. */
-int bem_pi_gate_x6_f32(const float* x, const float* ln_w, const float* ln_b, float ln_eps, const float* Wp_gate,
-                       const float* bias_gate, const float* dw_gate, const float* dwb_gate, float* g, int B, int C, int Hd,
-                       int H, int W, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Training step: backward of the Stage-II forward + optimizer, i.e. what

@@ -26,7 +26,6 @@ for (B, C, H, W) in [(64, 40, 128, 128), (64, 80, 64, 64), (64, 160, 32, 32)]:
     wo = d(torch.randn(C, Hd, generator=g) * Hd ** -0.5); bo = d(torch.randn(C, generator=g))
     perm = ops.gate_interleave(Hd, "cuda")
     Wg = ops.pack_pw_weight(wi[perm].contiguous(), x6=True); bg = bi[perm].contiguous()
-    wdg, bdg = ops.dw_gate_params(wd, bd, Hd)
     Wo = ops.pack_pw_weight(wo, x6=True); Wi = ops.pack_pw_weight(wi, x6=True)
     w10 = ops.dw_gate_params10(wd, bd, Hd)
     fused = lambda: ops.gdmlp_x6(x, lw, lb, 1e-6, Wg, bg, w10, Wo, bo, Hd)
@@ -37,9 +36,4 @@ for (B, C, H, W) in [(64, 40, 128, 128), (64, 80, 64, 64), (64, 160, 32, 32)]:
     err = (y - r).abs().max().item()
     print(f"C={C} {H}x{W}: max |fused - chain| = {err:.3e} (|chain| max {r.abs().max().item():.2f})")
     print(f"  chain (3 kernels): {timeit(chain):8.1f} us")
-    if C <= 48:
-        perm2 = ops.gate_order(Hd, "cuda")
-        Wg2 = ops.pack_pw_weight(wi[perm2].contiguous(), x6=True); bg2 = bi[perm2].contiguous()
-        pig = lambda: ops.pw_gemm(ops.pi_gate(x, lw, lb, 1e-6, Wg2, bg2, wdg, bdg, Hd), Wo, C, bias=bo, res=x)
-        print(f"  pi_gate + project_out: {timeit(pig):8.1f} us")
     print(f"  fused: {timeit(fused):8.1f} us")

@@ -13,11 +13,12 @@ def test_isa_audit_clean():
     ia = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(ia)
     ks = ia.audit_all()
-    assert len(ks) > 150, "kernel discovery broke"
+    assert len(ks) > 100, "kernel discovery broke"
     names = " ".join(k["name"] for k in ks)
     for must in ("ss2d_scan_rows_kernel<1024, 4, 1, 3, 8, true, 1>", "ss2d_scan_bwd_rows_kernel<512, 8, 4, 3>", "wgrad_kernel<1, 2, false, true>",
                  "pw_x6_stream_kernel<2, 2, false, true, false>", "ln_bwd_split_kernel<10, 4, false, true, true>", "wgrad_x6_kernel<2, 2>",
-                 "pi_gate_x6_kernel<3, 8, 4>", "dwact_bwd_kernel<2, true>"):
+                 "gdmlp_x6_kernel<3, 2, 2, false>", "gdmlp_x6_kernel<5, 3, 1, false>", "conv_rows_x6_kernel<2, 4, 2>",
+                 "conv_rows_x6_kernel<1, 3, 1>", "ss2d_front_x6_kernel<3, 40>", "dwact_bwd_kernel<2, true>"):
         assert must in names, f"default-dispatched kernel {must} not found in the build"
     bad = ia.violations(ks)
     assert not bad, "\n".join(bad)

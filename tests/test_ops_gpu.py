@@ -223,11 +223,9 @@ def test_dwconv_modes(ops, cfg):
 
 @pytest.mark.parametrize("cfg", [(2, 32, 32, 16, 20, 3, 1), (1, 11, 40, 9, 33, 3, 1), (1, 40, 16, 8, 8, 3, 1), (2, 40, 80, 16, 12, 4, 2),
                                  (1, 3, 40, 5, 7, 3, 1), (1, 80, 160, 6, 10, 4, 2), (1, 40, 3, 70, 40, 3, 1),
-                                 (1, 40, 80, 32, 64, 4, 2), (2, 80, 160, 16, 16, 4, 2), (1, 8, 24, 6, 4, 4, 2)])   # 4x4-s2 as 16 x6 taps
+                                 (1, 40, 80, 32, 64, 4, 2), (2, 80, 160, 16, 16, 4, 2), (1, 8, 24, 6, 4, 4, 2), (1, 40, 80, 12, 20, 4, 2)])   # 4x4-s2: row form / f32-MFMA (Wo = 10)
 def test_conv2d(ops, cfg, monkeypatch):
     B, Ci, Co, H, W, k, s = cfg
-    if k == 4 and Ci % 8 == 0 and H * W > 100:
-        monkeypatch.setattr(ops, "USE_CONV4_X6", True)         # also exercise the (default-off) 16-tap x6 form
     g = torch.Generator().manual_seed(Ci * Co)
     x, w, b = torch.randn(B, Ci, H, W, generator=g), torch.randn(Co, Ci, k, k, generator=g) * (Ci * k * k) ** -0.5, torch.randn(Co, generator=g)
     ref = F.conv2d(x, w, b, stride=s, padding=1)
@@ -363,44 +361,6 @@ def test_rejects_bad_arguments(ops):
 
 
 # ----------------------------------------------------------------------------- fused gdMlp ------
-@pytest.mark.parametrize("cfg", [(2, 40, 16, 12), (1, 16, 8, 8), (2, 8, 5, 7), (1, 80, 24, 33), (1, 160, 8, 8), (3, 40, 4, 4), (1, 40, 128, 128)])
-def test_gdmlp_fused_vs_oracle(ops, cfg):
-    """bem_gdmlp_fused_f32 (LN + project_in + dw3x3 + GELU gate + project_out + residual in one kernel)
-    vs oracle.gdmlp_ref on LN(x).  Tolerance 2e-4 rel / 5e-5 abs (two chained f32 GEMMs of depth C and 4C,
-    erf evaluated by the 1.5e-7-accurate A&S 7.1.26 form)."""
-    B, C, H, W = cfg
-    Hd = 4 * C
-    g = torch.Generator().manual_seed(C + H)
-    x = torch.randn(B, C, H, W, generator=g)
-    sd = {"project_in.weight": torch.randn(2 * Hd, C, 1, 1, generator=g) * C ** -0.5, "project_in.bias": 0.1 * torch.randn(2 * Hd, generator=g),
-          "dwconv.weight": torch.randn(2 * Hd, 1, 3, 3, generator=g) / 3, "dwconv.bias": 0.1 * torch.randn(2 * Hd, generator=g),
-          "project_out.weight": torch.randn(C, Hd, 1, 1, generator=g) * Hd ** -0.5, "project_out.bias": 0.1 * torch.randn(C, generator=g)}
-    lw, lb = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
-    ref = x + O.gdmlp_ref(sd, "", O.layernorm2d_ref(x, lw, lb))
-    Wpi = ops.pack_pw_weight_gate(dev(sd["project_in.weight"].reshape(2 * Hd, C)), Hd)
-    Wpo = ops.pack_pw_weight(dev(sd["project_out.weight"].reshape(C, Hd)), x6=False)
-    y = ops.gdmlp_fused(dev(x), dev(lw), dev(lb), 1e-5, Wpi, dev(sd["project_in.bias"]), dev(sd["dwconv.weight"].reshape(2 * Hd, 9)),
-                        dev(sd["dwconv.bias"]), Wpo, dev(sd["project_out.bias"]), Hd)
-    close(y, ref, 2e-4, 5e-5, f"gdmlp fused {cfg}")
-
-
-def test_gdmlp_fused_per_batch_weights(ops):
-    B, C, H, W = 3, 16, 9, 10
-    Hd = 4 * C
-    g = torch.Generator().manual_seed(77)
-    x = torch.randn(B, C, H, W, generator=g)
-    wi, bi = torch.randn(B, 2 * Hd, C, generator=g) * 0.25, 0.1 * torch.randn(B, 2 * Hd, generator=g)
-    wd, bd = torch.randn(B, 2 * Hd, 1, 3, 3, generator=g) / 3, 0.1 * torch.randn(B, 2 * Hd, generator=g)
-    wo, bo = torch.randn(B, C, Hd, generator=g) * 0.1, 0.1 * torch.randn(B, C, generator=g)
-    lw, lb = torch.ones(C), torch.zeros(C)
-    ref = torch.cat([x[i:i + 1] + O.gdmlp_ref({"project_in.weight": wi[i][:, :, None, None], "project_in.bias": bi[i], "dwconv.weight": wd[i],
-                                               "dwconv.bias": bd[i], "project_out.weight": wo[i][:, :, None, None], "project_out.bias": bo[i]},
-                                              "", O.layernorm2d_ref(x[i:i + 1], lw, lb)) for i in range(B)])
-    y = ops.gdmlp_fused(dev(x), dev(lw), dev(lb), 1e-5, ops.pack_pw_weight_gate(dev(wi), Hd), dev(bi), dev(wd.reshape(B, 2 * Hd * 9)), dev(bd),
-                        ops.pack_pw_weight(dev(wo), x6=False), dev(bo), Hd)
-    close(y, ref, 2e-4, 5e-5, "gdmlp fused per-batch")
-
-
 # ----------------------------------------------------------------------------- scan backward ----
 @pytest.mark.parametrize("tag", list("abcde"))
 def test_selective_scan_bwd_golden(ops, tag):
@@ -577,64 +537,6 @@ def test_pw_gemm_x6_generic_epilogue_full_size(ops):
     ref = torch.einsum("mk,bkhw->bmhw", w, x) + b[None, :, None, None]
     y = ops.pw_gemm(dev(x), ops.pack_pw_weight(dev(w), x6=True), 5, bias=dev(b))
     assert int(((y.cpu() - ref).abs() > 1e-3).sum()) == 0
-
-
-@pytest.mark.parametrize("cfg", [(2, 40, 16, 16, 12, False), (1, 40, 160, 128, 128, True), (2, 8, 32, 5, 8, True), (1, 80, 320, 9, 30, False), (3, 20, 24, 4, 6, True)])
-def test_gate_proj_vs_unfused_chain(ops, cfg):
-    """bem_gate_proj_x6_f32 (depthwise 3x3 + GELU gate inside the project_out loader) against dwconv3x3(mode 2) + pw_gemm and
-    against torch: borders, rows spanning several waves, Hd not a multiple of 16, per-sample parameters, residual + bias."""
-    B, C, Hd, H, W, per_b = cfg
-    g = torch.Generator().manual_seed(C * Hd + H)
-    hsrc = torch.randn(B, 2 * Hd, H, W, generator=g)
-    h = ops.empty_padded((B, 2 * Hd, H, W), "cuda"); h.copy_(hsrc)
-    wd = torch.randn(*((B,) if per_b else ()), 2 * Hd, 1, 3, 3, generator=g) / 3
-    bd = 0.2 * torch.randn(*((B,) if per_b else ()), 2 * Hd, generator=g)
-    wo = torch.randn(*((B,) if per_b else ()), C, Hd, generator=g) * Hd ** -0.5
-    bo = torch.randn(*((B,) if per_b else ()), C, generator=g)
-    res = torch.randn(B, C, H, W, generator=g)
-    Wp = ops.pack_pw_weight(dev(wo), x6=True)
-    y = ops.gate_proj(h, dev(wd), dev(bd), Wp, C, bias=dev(bo), res=dev(res))
-    chain = ops.pw_gemm(ops.dwconv3x3(h.contiguous(), dev(wd), dev(bd), 2), Wp, C, bias=dev(bo), res=dev(res))
-    close(y, chain, 1e-4, 2e-5, f"gate_proj vs chain {cfg}")
-    ref = []
-    for i in range(B):
-        wi, bi = (wd[i], bd[i]) if per_b else (wd, bd)
-        t = F.conv2d(hsrc[i:i + 1], wi, bi, padding=1, groups=2 * Hd)
-        gg = F.gelu(t[:, :Hd]) * t[:, Hd:]
-        ref.append(F.conv2d(gg, (wo[i] if per_b else wo)[:, :, None, None], bo[i] if per_b else bo) + res[i:i + 1])
-    close(y, torch.cat(ref), 1e-4, 2e-5, f"gate_proj vs torch {cfg}")
-
-
-@pytest.mark.parametrize("cfg", [(2, 40, 160, 16, 64, True), (4, 40, 160, 128, 128, True), (2, 24, 32, 13, 45, True), (1, 7, 16, 8, 32, False),
-                                 (3, 48, 96, 5, 3, True), (1, 16, 64, 33, 70, True), (2, 80, 320, 64, 64, True), (1, 64, 48, 9, 37, False),
-                                 (2, 72, 16, 4, 32, True)])
-def test_pi_gate_vs_unfused_chain(ops, cfg, monkeypatch):
-    """bem_pi_gate_x6_f32 (LayerNorm + project_in + depthwise 3x3 + GELU gate, the 2Hd-channel tensor only in LDS) against the
-    two-kernel chain pw_gemm(LN) -> dwconv3x3(mode 2) and against torch in float64: image borders inside and across tiles,
-    planes that are not a multiple of the 8 x 32 tile, C not a multiple of 16, no biases, the bench's level-0 shape."""
-    B, C, Hd, H, W, bias = cfg
-    monkeypatch.setattr(ops, "PI_GATE_MAXC", 80)       # the C > 48 form (4-row tiles, 8 waves, weights through LDS) is off by default: slower
-    g = torch.Generator().manual_seed(C * Hd + H)
-    x = torch.randn(B, C, H, W, generator=g) * 2 + 0.3
-    lw, lb = 1 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
-    wi = torch.randn(2 * Hd, C, generator=g) * C ** -0.5
-    bi = 0.3 * torch.randn(2 * Hd, generator=g) if bias else None
-    wd = torch.randn(2 * Hd, 1, 3, 3, generator=g) / 3
-    bd = 0.2 * torch.randn(2 * Hd, generator=g) if bias else None
-    perm = ops.gate_order(Hd, "cpu")
-    Wg = ops.pack_pw_weight(dev(wi[perm].contiguous()), x6=True)
-    wdg, bdg = ops.dw_gate_params(dev(wd), None if bd is None else dev(bd), Hd)
-    y = ops.pi_gate(dev(x), dev(lw), dev(lb), 1e-6, Wg, None if bi is None else dev(bi[perm].contiguous()), wdg, bdg, Hd)
-    t = ops.pw_gemm(dev(x), ops.pack_pw_weight(dev(wi), x6=True), 2 * Hd, ln=(dev(lw), dev(lb)), ln_eps=1e-6, bias=None if bi is None else dev(bi))
-    chain = ops.dwconv3x3(t, dev(wd), None if bd is None else dev(bd), 2)
-    close(y, chain, 1e-4, 2e-5, f"pi_gate vs chain {cfg}")
-    xd = x.double()
-    mu, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
-    n = (xd - mu) / (var + 1e-6).sqrt() * lw.double()[None, :, None, None] + lb.double()[None, :, None, None]
-    tt = F.conv2d(n, wi.double()[:, :, None, None], None if bi is None else bi.double())
-    hh = F.conv2d(tt, wd.double(), None if bd is None else bd.double(), padding=1, groups=2 * Hd)
-    ref = (F.gelu(hh[:, :Hd]) * hh[:, Hd:]).float()
-    close(y, ref, 1e-4, 2e-5, f"pi_gate vs torch f64 {cfg}")
 
 
 @pytest.mark.parametrize("cfg", [(2, 40, 160, 16, 64, True), (4, 40, 160, 128, 128, True), (2, 24, 32, 13, 45, True), (1, 7, 16, 8, 32, False),
@@ -864,3 +766,25 @@ def test_ss2d_front_x6_vs_chain_and_float64(ops, cfg):
     c64 = F.silu(F.conv2d(tt, wd.double(), None if bd is None else bd.double(), padding=1, groups=C))
     close(xc, c64.float(), 1e-4, 4e-5, f"ss2d_front xc vs torch f64 {cfg}")
     close(xd, F.conv2d(c64, wx.double()[:, :, None, None]).float(), 1e-4, 4e-5, f"ss2d_front xd vs torch f64 {cfg}")
+
+
+@pytest.mark.parametrize("cfg", [(71680, 32, 32, 32, 2), (131072, 32, 64, 0, 0), (71680, 96, 40, 40, 2)])
+def test_x6_gemm_bias_epilogue_under_load(ops, cfg):
+    """Regression for the round-3 corruption: the decomposition's attention-fuse GEMM (M = 32, K = 32 + 32, cat input) at the config-5 plane
+    size launches 280 workgroups, i.e. two on some CUs, and a few times per run 16 outputs of one row (lanes 48..63 of a wave) came out
+    WITHOUT their bias: a packed add took the high register of the freshly global-loaded bias pair for its low result and read the
+    pair's pre-load content (fixed by a VALU copy, guarded by scripts/isa_audit.py check 2).  Six launches each,
+    every output against float64."""
+    L, M, K1, K2, mode = cfg
+    g = torch.Generator().manual_seed(L + M)
+    x1 = dev(torch.randn(1, K1, L, generator=g))
+    x2 = dev(torch.randn(1, K2, L, generator=g)) if K2 else None
+    W = torch.randn(M, K1 + K2, generator=g) * 0.1
+    bias = torch.randn(M, generator=g)
+    Wp = ops.pack_pw_weight(dev(W), x6=True)
+    xin = torch.cat([x1, x2], 1)[0] if K2 else x1[0]
+    ref = (dev(W).double() @ xin.double() + dev(bias).double()[:, None])
+    for rep in range(6):
+        out = ops.pw_gemm(x1, Wp, M, x2=x2, in_mode=mode, bias=dev(bias))
+        bad = int(((out[0].double() - ref).abs() > 1e-4).sum())
+        assert bad == 0, f"{cfg} launch {rep}: {bad} outputs off by more than 1e-4"
