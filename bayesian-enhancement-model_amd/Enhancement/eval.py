@@ -80,6 +80,16 @@ def main(argv=None):
     from basicsr.utils.options import parse
     from bem.pipeline import BEMPipeline
     from bem.scorers import FullReference
+    # one process per GPU under `python -m torch.distributed.run --nproc-per-node N Enhancement/eval.py ...`: the driver feeds ONE image at a
+    # time (eval.py:160-222), so the N Bayesian samples of that image are what gets sharded (sample-major, bem.dist); every rank holds the
+    # gathered candidates, rank 0 writes the files
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if not dist.is_initialized():
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", torch.cuda.current_device()))
     torch.manual_seed(args.seed)
     np.random.seed(args.seed)
     opt, cond_opt = parse(args.opt, is_train=False), parse(args.cond_opt, is_train=False)
@@ -104,7 +114,7 @@ def main(argv=None):
             if args.target_dir:
                 tgt = torch.from_numpy(load_rgb(os.path.join(args.target_dir, name))).permute(2, 0, 1)[None].cuda()
             r = pipe.enhance(img, tgt, args.num_samples, gt_mean=args.GT_mean, deterministic=args.deterministic, scorer=scorer,
-                             monte_carlo=args.Monte_Carlo, seed=args.seed + i)
+                             monte_carlo=args.Monte_Carlo, seed=args.seed + i, shard=(rank, world) if world > 1 else None)
             best = r["best_images"]
             if tgt is not None:
                 from bem import ops
@@ -113,7 +123,14 @@ def main(argv=None):
                 ssim.append(float(ops.ssim(best.contiguous(), tgt.contiguous(), 1)[0]))
                 if args.Monte_Carlo:
                     mc_psnr.append(float(r["mc_psnr"][0])); mc_ssim.append(float(r["mc_ssim"][0]))
-            save_rgb(os.path.join(result_dir, os.path.splitext(name)[0] + ".png"), best[0].permute(1, 2, 0).cpu().numpy())
+            if rank == 0:
+                save_rgb(os.path.join(result_dir, os.path.splitext(name)[0] + ".png"), best[0].permute(1, 2, 0).cpu().numpy())
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return dict(psnr=psnr, ssim=ssim, mc_psnr=mc_psnr, mc_ssim=mc_ssim, result_dir=result_dir)
     print(f"running time: {time.perf_counter() - t0:.4f} sec")
     with open(os.path.join(result_dir, "result.txt"), "w") as f:
         if args.target_dir:

@@ -1,6 +1,6 @@
 // Pointwise (1x1) channel-mix GEMM, f32 in / f32 out, products on the bf16 matrix cores as a 3-limb expansion.
 //
-//   out[b][m][p] = act(sum_k W[m][k] * pro(x)[b][k][p] + bias[m]) + res[b][m][p]        (same contract as pw_gemm.hip)
+//   out[b][m][p] = act(sum_k W[m][k] * pro(x)[b][k][p] + bias[m]) + res[b][m][p]        (argument block bem_pw_args, include/bem_hip.h)
 //
 // Why: v_mfma_f32_32x32x2_f32 delivers 64 FLOP / cycle / SIMD, v_mfma_f32_32x32x16_bf16 1024.  Every f32 operand is
 // split exactly into three bf16 limbs  v = h + m + l  (round-to-nearest at each step, exact f32 residuals), and a
@@ -42,7 +42,7 @@ struct PwX {
 };
 
 
-// Branch-free input fetch (see pw_gemm.hip): always a clamped, valid address, value masked afterwards.
+// Branch-free input fetch: always a clamped, valid address, value masked afterwards.
 // Returns pro-input channel ch at this lane's NSUB pixels (pixel index pc clamped by the caller, keep[t] per pixel).
 template <int NSUB, bool SUM, bool VEC>
 __device__ __forceinline__ void ldx(const PwX& k, int b, int ch, int pc, const bool (&keep)[NSUB], float (&o)[NSUB]) {

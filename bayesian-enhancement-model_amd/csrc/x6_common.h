@@ -1,5 +1,5 @@
 // Shared device helpers of the x6 (3-limb bf16) matrix-core kernels: operand typedefs, the exact limb split, the six-product MAC
-// and the XCD-aware tile order.  Included by pw_gemm_x6.hip and pi_gate_x6.hip; see the header comment of pw_gemm_x6.hip.
+// and the XCD-aware tile order.  Included by pw_gemm_x6.hip, gdmlp_x6.hip, conv_rows_x6.hip and ss2d_front_x6.hip; see the header comment of pw_gemm_x6.hip.
 #pragma once
 #include "bem_common.h"
 

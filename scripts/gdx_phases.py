@@ -1,6 +1,5 @@
 """Timing anatomy of bem_gdmlp_x6_f32 (level-0 shape, C = 40, 128 x 128 planes): batch sizes that put 1 / 2 / 3 workgroups on a CU
-(B = 2, 4, 6 -> 256, 512, 768 workgroups) and the bench's B = 64, each with phases switched off by BEM_GDX_DBG
-(1: no phase A, 2: no phase B, 4: no phase C, 8: no weight DMA).   python scripts/gdx_phases.py [reps]"""
+(B = 2, 4, 6 -> 256, 512, 768 workgroups) and the bench's B = 64.   python scripts/gdx_phases.py [reps]"""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bayesian-enhancement-model_amd"))
 from bem import ops
@@ -33,7 +32,5 @@ for (C, H, W) in shapes:
         x = d(torch.randn(B, C, H, W, generator=g))
         row = []
         for dbg in (0,):
-            os.environ["BEM_GDX_DBG"] = str(dbg)
-            row.append(f"{dbg}:{timeit(lambda: ops.gdmlp_x6(x, lw, lb, 1e-6, Wg, bg, w10, Wo, bo, Hd)):7.1f}")
-        print(f"C={C} {H}x{W} B={B:3d} ({B * tiles:5d} workgroups)  us by dbg  " + "  ".join(row), flush=True)
-os.environ["BEM_GDX_DBG"] = "0"
+            row.append(f"{timeit(lambda: ops.gdmlp_x6(x, lw, lb, 1e-6, Wg, bg, w10, Wo, bo, Hd)):7.1f}")
+        print(f"C={C} {H}x{W} B={B:3d} ({B * tiles:5d} workgroups)  us  " + "  ".join(row), flush=True)

@@ -452,3 +452,34 @@ def test_bench_step_reproducible_under_full_load():
         assert d <= 2e-6, d
         assert float((p - runs[0][1]).abs().max()) <= 1e-4
     assert torch.isfinite(runs[0][0]).all()
+
+
+def test_sample_major_blocks_equal_unsharded_candidates():
+    """What a rank computes under sample-major sharding (bem.dist, Enhancement/eval.py under torchrun): `BEMPipeline.candidates` for a block
+    [lo, hi) of the N samples with the epsilons / noise of ALL rows handed in.  The blocks of a two-rank split (N = 5: 3 + 2), put back in
+    (image, sample) order exactly as `gather_samples` does, must equal the unsharded call: candidates, conditions and scores -- hence the
+    same first-maximum selection (the gather itself runs on gloo in tests/test_dist_cpu.py, the collective on RCCL in the world-1 test)."""
+    from bem.dist import shard_samples
+    from bem.pipeline import BEMPipeline, build_nets, synthetic_pair
+    net1, net2 = build_nets(n_feat=16, num_blocks=(1, 1, 1), seed=100, device="cuda")
+    sd1 = net1.state_dict()
+    lq, gt = synthetic_pair((2, 3, 64, 64), seed=9)
+    B, N, world = 2, 5, 2
+    g = torch.Generator().manual_seed(3)
+    eps = {(k[:-len("mu_weight")] + "weight" if k.endswith("mu_weight") else k[:-len("mu_bias")] + "bias"): torch.randn((B * N,) + tuple(v.shape), generator=g).cuda()
+           for k, v in sd1.items() if k.endswith(("mu_weight", "mu_bias"))}
+    noise = torch.randn(B * N, 3, 4, 4, generator=g).cuda()
+    pipe = BEMPipeline(net1, net2, 16, 0.1)
+    full = pipe.candidates(lq.cuda(), gt.cuda(), N, True, eps=eps, noise=noise)
+    parts = []
+    for rank in range(world):
+        lo, hi = shard_samples(N, rank, world)
+        parts.append((lo, hi, pipe.candidates(lq.cuda(), gt.cuda(), hi - lo, True, eps=eps, noise=noise, rank=rank, sample_offset=lo, total_samples=N)))
+    for key in ("final", "psnr", "conds"):
+        rows = []
+        for b in range(B):
+            for lo, hi, r in parts:
+                n = hi - lo
+                rows.append(r[key][b * n:(b + 1) * n])
+        got = torch.cat(rows)
+        close(got, full[key], 1e-5, 1e-6, f"sample-major {key}")
