@@ -531,15 +531,10 @@ __global__ __launch_bounds__(NT, MINW) void ss2d_scan_rows_kernel(
                     const int sl = min(lane, NW - 1), src = dir ? NW - 1 - sl : sl;      // always a valid pair; lanes >= NW hold the identity
                     const float Pl = ag[2 * src], Sl = ag[2 * src + 1];
                     float Pw = lane < NW ? Pl : 1.f, Sw = lane < NW ? Sl : 0.f;
-#define BEM_ROW_STEP(CTRL)                                                             \
-    {                                                                                  \
-        const float Pp = dpp_mov<CTRL, 0xf>(1.f, Pw), Sp = dpp_mov<CTRL, 0xf>(0.f, Sw); \
-        Sw = fmaf(Pw, Sp, Sw);                                                         \
-        Pw = Pw * Pp;                                                                  \
-    }
-                    BEM_ROW_STEP(0x111) BEM_ROW_STEP(0x112)
-                    if (NW > 4) { BEM_ROW_STEP(0x114) }
-                    if (NW > 8) { BEM_ROW_STEP(0x118) }
+#define BEM_ROW_STEP(DPP) asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 " DPP "\n\tv_mul_f32_dpp %1, %1, %1 " DPP : "+v"(Sw), "+v"(Pw))
+                    BEM_ROW_STEP("row_shr:1 row_mask:0xf bank_mask:0xf"); BEM_ROW_STEP("row_shr:2 row_mask:0xf bank_mask:0xf");
+                    if (NW > 4) BEM_ROW_STEP("row_shr:4 row_mask:0xf bank_mask:0xf");
+                    if (NW > 8) BEM_ROW_STEP("row_shr:8 row_mask:0xf bank_mask:0xf");
 #undef BEM_ROW_STEP
                     const int rw = dir ? NW - 1 - wave : wave;                 // this wave's place in scan order (uniform)
                     const float Pt = lane_bcast(Pw, NW - 1), St = lane_bcast(Sw, NW - 1);
@@ -793,23 +788,13 @@ extern "C" int bem_ss2d_scan_strided_f32(const float* x0, const float* x1, const
 #define BEM_SS2D_CHUNKS(RT) ss2d_scan_chunks_kernel<256, 8, RT><<<grid, 256, 0, s>>>(x0, x1, xd0, xd1, dtw, dtb, A, Ds, y0, y1, B, C, L, R, xbs0, xbs1)
     const bool al = (((uintptr_t)x0 | (uintptr_t)x1 | (uintptr_t)xd0 | (uintptr_t)xd1 | (uintptr_t)y0 | (uintptr_t)y1) & 15) == 0;
     // channel-blocked whole-row forms for the plane sizes and dt_ranks of a 256x256 image (n_feat 40: C = 40 / 80 / 160)
-    static const int variant = getenv("BEM_SCAN_VARIANT") ? atoi(getenv("BEM_SCAN_VARIANT")) : 1;
 #define BEM_SS2D_ROWS(NT, T, CB, RT, MW) do { ss2d_scan_rows_kernel<NT, T, CB, RT, MW, false><<<((C + CB - 1) / CB) * B * 2, NT, 0, s>>>( \
         x0, x1, xd0, xd1, dtw, dtb, A, Ds, y0, y1, B, C, xbs0, xbs1, 0); return bem_check_launch("ss2d_scan"); } while (0)
-    if (al && variant) {
-        if (L == 1024 && R == 10) { if (variant == 2) BEM_SS2D_ROWS(256, 1, 2, 10, 6); else if (variant == 3) BEM_SS2D_ROWS(256, 1, 4, 10, 4); else BEM_SS2D_ROWS(256, 1, 4, 10, 5); }
-        if (L == 4096 && R == 5) {
-            if (variant == 2) BEM_SS2D_ROWS(512, 2, 4, 5, 4); else if (variant == 3) BEM_SS2D_ROWS(256, 4, 2, 5, 5);
-            else if (variant == 4) BEM_SS2D_ROWS(1024, 1, 4, 5, 4); else if (variant == 5) BEM_SS2D_ROWS(1024, 1, 1, 5, 8);
-            else if (variant == 6) BEM_SS2D_ROWS(1024, 1, 2, 5, 6); else if (variant == 7) BEM_SS2D_ROWS(256, 4, 4, 5, 4);
-            else BEM_SS2D_ROWS(512, 2, 2, 5, 6);       // measured best of the sweep (139 us; 256 x 4 tiles x 4 channels: 157)
-        }
-        if (L == 16384 && R == 3) {
-            if (variant == 2) BEM_SS2D_ROWS(1024, 4, 2, 3, 4); else if (variant == 3) BEM_SS2D_ROWS(512, 8, 2, 3, 4);
-            else if (variant == 4) BEM_SS2D_ROWS(1024, 4, 1, 3, 4); else if (variant == 5) BEM_SS2D_ROWS(1024, 4, 1, 3, 8);
-            else if (variant == 6) BEM_SS2D_ROWS(512, 8, 1, 3, 4); else if (variant == 7) BEM_SS2D_ROWS(1024, 4, 4, 3, 4);
-            else BEM_SS2D_ROWS(1024, 4, 1, 3, 8);      // 64 VGPRs: two 1024-thread workgroups per CU (measured best: 319 us)
-        }
+    // the tilings that won the round-1 / round-2 sweeps (the other 14 instantiations went with their A/B switch in round 3)
+    if (al) {
+        if (L == 1024 && R == 10) BEM_SS2D_ROWS(256, 1, 4, 10, 5);
+        if (L == 4096 && R == 5) BEM_SS2D_ROWS(512, 2, 2, 5, 6);       // 139 us (256 x 4 tiles x 4 channels: 157)
+        if (L == 16384 && R == 3) BEM_SS2D_ROWS(1024, 4, 1, 3, 8);     // 64 VGPRs: two 1024-thread workgroups per CU
     }
 #undef BEM_SS2D_ROWS
     // whole-row forms: x read once, y written once.  (A 1024 x 16 form for L = 16384 measured slower than the chunked
@@ -917,21 +902,13 @@ extern "C" int bem_ss2d_scan_rm_f32(const float* x, const float* xd0, const floa
     BEM_REQUIRE((((uintptr_t)x | (uintptr_t)xd0 | (uintptr_t)xd1 | (uintptr_t)y0 | (uintptr_t)y1) & 15) == 0, "ss2d_scan_rm: 16-byte alignment");
     if (B == 0) return BEM_OK;
     hipStream_t s = (hipStream_t)stream;
-    static const int split = getenv("BEM_SCAN_SPLIT") ? atoi(getenv("BEM_SCAN_SPLIT")) : 1;
 #define BEM_TR(NT, T, CB, RT, MW, ORI) launch_rows_tr<NT, T, CB, RT, MW, ORI>(x, xd0, xd1, dtw, dtb, A, Ds, y0, y1, B, C, H, W, xbs0, xbs1, s)
     if (L == 16384) {
-        if (!split) return BEM_TR(1024, 4, 1, 3, 8, -1);
-        const int rc = BEM_TR(1024, 4, 1, 3, 8, 0);          // measured: 2 x 171 us against 372 us for the combined (spilling) kernel
+        // two single-orientation launches: 2 x 172 us, no scratch; the combined kernel needs both orientations' state at once and spilled (372 us)
+        const int rc = BEM_TR(1024, 4, 1, 3, 8, 0);
         return rc ? rc : BEM_TR(1024, 4, 1, 3, 8, 1);
     }
-    if (L == 4096) {
-        if (split < 2) return BEM_TR(512, 2, 2, 5, 6, -1);
-        const int rc = BEM_TR(512, 2, 2, 5, 6, 0);
-        if (rc) return rc;
-        if (split == 2) return BEM_TR(512, 2, 2, 5, 5, 1);
-        if (split == 3) return BEM_TR(512, 2, 1, 5, 8, 1);
-        return BEM_TR(1024, 1, 2, 5, 6, 1);
-    }
+    if (L == 4096) return BEM_TR(512, 2, 2, 5, 6, -1);       // combined: 143 us against 152 us for the best split
     return BEM_TR(256, 1, 4, 10, 5, -1);
 #undef BEM_TR
 }

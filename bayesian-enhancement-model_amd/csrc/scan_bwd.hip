@@ -261,13 +261,14 @@ __global__ __launch_bounds__(NT) void ss2d_scan_bwd_rows_kernel(
 #pragma unroll
             for (int r = 0; r < R; ++r) dq[r] = *reinterpret_cast<const float4*>(xd + (int64_t)r * L + pos);
             const float4 Bq = *reinterpret_cast<const float4*>(xd + (int64_t)R * L + pos);
-            const float Bv[4] = {Bq.x, Bq.y, Bq.z, Bq.w};
+            // loaded values that meet packed-f32 arithmetic go through a VALU copy first (scripts/isa_audit.py check 2)
+            const float Bv[4] = {valu_copy(Bq.x), valu_copy(Bq.y), valu_copy(Bq.z), valu_copy(Bq.w)};
 #pragma unroll
             for (int ch = 0; ch < CB; ++ch) {
                 const int c = min(g * CB + ch, C - 1);
                 __builtin_amdgcn_sched_barrier(0);
                 const float4 xq = *reinterpret_cast<const float4*>(xb + (int64_t)c * L + pos);
-                const float xv[4] = {xq.x, xq.y, xq.z, xq.w};
+                const float xv[4] = {valu_copy(xq.x), valu_copy(xq.y), valu_copy(xq.z), valu_copy(xq.w)};
                 const float* wd = dtw + ((int64_t)kd * C + c) * R;
                 const float bias = dtb[kd * C + c], Ak = A[kd * C + c];
                 float z[4];
@@ -314,7 +315,8 @@ __global__ __launch_bounds__(NT) void ss2d_scan_bwd_rows_kernel(
             for (int r = 0; r < R; ++r) dq[r] = *reinterpret_cast<const float4*>(xd + (int64_t)r * L + pos);
             const float4 Bq = *reinterpret_cast<const float4*>(xd + (int64_t)R * L + pos);
             const float4 Cq = *reinterpret_cast<const float4*>(xd + (int64_t)(R + 1) * L + pos);
-            const float Bv[4] = {Bq.x, Bq.y, Bq.z, Bq.w}, Cv[4] = {Cq.x, Cq.y, Cq.z, Cq.w};
+            const float Bv[4] = {valu_copy(Bq.x), valu_copy(Bq.y), valu_copy(Bq.z), valu_copy(Bq.w)},
+                        Cv[4] = {valu_copy(Cq.x), valu_copy(Cq.y), valu_copy(Cq.z), valu_copy(Cq.w)};
             float acc[R + 2][4];
 #pragma unroll
             for (int q = 0; q < R + 2; ++q)
@@ -327,7 +329,8 @@ __global__ __launch_bounds__(NT) void ss2d_scan_bwd_rows_kernel(
                 __builtin_amdgcn_sched_barrier(0);
                 const float4 xq = *reinterpret_cast<const float4*>(xb + (int64_t)c * L + pos);
                 const float4 gq = *reinterpret_cast<const float4*>(dyb + (int64_t)c * L + pos);
-                const float xv[4] = {xq.x, xq.y, xq.z, xq.w}, dy[4] = {gq.x, gq.y, gq.z, gq.w};
+                const float xv[4] = {valu_copy(xq.x), valu_copy(xq.y), valu_copy(xq.z), valu_copy(xq.w)},
+                            dy[4] = {valu_copy(gq.x), valu_copy(gq.y), valu_copy(gq.z), valu_copy(gq.w)};
                 const float* wd = dtw + ((int64_t)kd * C + c) * R;
                 const float bias = dtb[kd * C + c], Ak = A[kd * C + c], Dk = Ds[kd * C + c];
                 float wr[R];

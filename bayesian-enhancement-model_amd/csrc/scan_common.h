@@ -126,23 +126,28 @@ __device__ __forceinline__ float dpp_mov(float old, float v) {
 __device__ __forceinline__ float lane_bcast(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
-#define BEM_SCAN_STEP(CTRL, RM)                                         \
-    {                                                                   \
-        const float Pp = dpp_mov<CTRL, RM>(1.f, P), Sp = dpp_mov<CTRL, RM>(0.f, S); \
-        S = fmaf(P, Sp, S);                                             \
-        P = P * Pp;                                                     \
-    }
+// One step of the lane scan of affine maps h -> P h + S: (P, S) <- (P, S) o (P, S)[source lane], i.e. S = P S' + S, P = P P'.
+// Both halves are ONE DPP instruction each: the DPP operand is the instruction's own src0, and a lane without a source lane (row
+// boundary, masked row) is simply not written -- the identity of the composition.  The builtin form (update_dpp with old = 1 / 0,
+// then fma / mul) costs six instructions per step (v_mov old, v_mov_dpp, twice, + fma + mul), a third of the whole scan kernel.
+// s_nop 1: a DPP read of a VGPR needs two wait states after the VALU write of that VGPR (gfx9 hazard; the compiler cannot see into
+// the asm, and S / P are written by the instruction right before the block).
+#define BEM_SCAN_STEP(DPP)                                                                                   \
+    asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 " DPP "\n\tv_mul_f32_dpp %1, %1, %1 " DPP : "+v"(S), "+v"(P))
 // inclusive scan of the per-lane affine maps (P, S) in ascending (REV = false) / descending (REV = true) lane order;
 // returns the exclusive map (Pe, Se) of every lane and leaves the wavefront total in lane 63 (0 for REV).
 template <bool REV>
 __device__ __forceinline__ void wave_scan_affine(float& P, float& S, float& Pe, float& Se) {
     if (!REV) {
-        BEM_SCAN_STEP(0x111, 0xf) BEM_SCAN_STEP(0x112, 0xf) BEM_SCAN_STEP(0x114, 0xf) BEM_SCAN_STEP(0x118, 0xf)   // row_shr 1,2,4,8
-        BEM_SCAN_STEP(0x142, 0xa) BEM_SCAN_STEP(0x143, 0xc)                                                       // row_bcast 15 / 31
+        BEM_SCAN_STEP("row_shr:1 row_mask:0xf bank_mask:0xf"); BEM_SCAN_STEP("row_shr:2 row_mask:0xf bank_mask:0xf");
+        BEM_SCAN_STEP("row_shr:4 row_mask:0xf bank_mask:0xf"); BEM_SCAN_STEP("row_shr:8 row_mask:0xf bank_mask:0xf");
+        BEM_SCAN_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf"); BEM_SCAN_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf");
+        asm volatile("s_nop 1");              // the compiler's own DPP moves below read P / S right behind the asm writes
         Pe = dpp_mov<0x138, 0xf>(1.f, P);   // wave_shr 1
         Se = dpp_mov<0x138, 0xf>(0.f, S);
     } else {
-        BEM_SCAN_STEP(0x101, 0xf) BEM_SCAN_STEP(0x102, 0xf) BEM_SCAN_STEP(0x104, 0xf) BEM_SCAN_STEP(0x108, 0xf)   // row_shl 1,2,4,8
+        BEM_SCAN_STEP("row_shl:1 row_mask:0xf bank_mask:0xf"); BEM_SCAN_STEP("row_shl:2 row_mask:0xf bank_mask:0xf");
+        BEM_SCAN_STEP("row_shl:4 row_mask:0xf bank_mask:0xf"); BEM_SCAN_STEP("row_shl:8 row_mask:0xf bank_mask:0xf");
         const int lane = threadIdx.x & 63;
         {   // rows 0 / 2 append the suffix of rows 1 / 3 (their lane 16 / 48)
             const float P16 = lane_bcast(P, 16), S16 = lane_bcast(S, 16), P48 = lane_bcast(P, 48), S48 = lane_bcast(S, 48);
@@ -184,15 +189,10 @@ __device__ __forceinline__ float cross_wave_affine(float P, float S, float* ag, 
     const int sl = min(lane, NW - 1), src = REV ? NW - 1 - sl : sl;
     const float Pl = ag[2 * src], Sl = ag[2 * src + 1];
     float Pw = lane < NW ? Pl : 1.f, Sw = lane < NW ? Sl : 0.f;
-#define BEM_ROW_STEP(CTRL)                                                             \
-    {                                                                                  \
-        const float Pp = dpp_mov<CTRL, 0xf>(1.f, Pw), Sp = dpp_mov<CTRL, 0xf>(0.f, Sw); \
-        Sw = fmaf(Pw, Sp, Sw);                                                         \
-        Pw = Pw * Pp;                                                                  \
-    }
-    BEM_ROW_STEP(0x111) BEM_ROW_STEP(0x112)
-    if (NW > 4) { BEM_ROW_STEP(0x114) }
-    if (NW > 8) { BEM_ROW_STEP(0x118) }
+#define BEM_ROW_STEP(DPP) asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 " DPP "\n\tv_mul_f32_dpp %1, %1, %1 " DPP : "+v"(Sw), "+v"(Pw))
+    BEM_ROW_STEP("row_shr:1 row_mask:0xf bank_mask:0xf"); BEM_ROW_STEP("row_shr:2 row_mask:0xf bank_mask:0xf");
+    if (NW > 4) BEM_ROW_STEP("row_shr:4 row_mask:0xf bank_mask:0xf");
+    if (NW > 8) BEM_ROW_STEP("row_shr:8 row_mask:0xf bank_mask:0xf");
 #undef BEM_ROW_STEP
     const int rw = REV ? NW - 1 - wave : wave;
     const float Pt = lane_bcast(Pw, NW - 1), St = lane_bcast(Sw, NW - 1);

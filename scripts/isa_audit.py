@@ -43,10 +43,6 @@ ALLOW_SCRATCH = {
     r"pw_x6_stream_kernel<3, 1,": "three M-tiles x one pixel sub-tile: measured variant kept for A/B, not dispatched by default",
     r"pw_x6_stream_kernel<2, 2, (true|false), false,": "VEC = false: odd plane sizes only (tests, ragged crops)",
     r"pw_x6_stream_kernel<2, 2, true, true, true>": "sum input + LayerNorm at K > 160: not reached by the shipped widths (n_feat 40: K <= 160 uses the resident kernel)",
-    r"ss2d_scan_rows_kernel<.*, false, -1>": "transposed-tensor scan forms: only with BEM_SCAN_RM=0 / BEM_SCAN_VARIANT sweeps",
-    r"ss2d_scan_rows_kernel<1024, 4, 1, 3, 8, true, -1>": "combined-orientation L = 16384 form: only with BEM_SCAN_SPLIT=0 (default = two scratch-free launches)",
-    r"ss2d_scan_rows_kernel<512, 2, 2, 5, 6, true, -1>": "L = 4096 combined form: 12 B; measured 145 us against 152 us for the best scratch-free split (profiles/r02)",
-    r"ss2d_scan_rows_kernel<512, 2, [12], 5, [58], true, 1>|ss2d_scan_rows_kernel<1024, 1, 2, 5, 6, true, 1>": "L = 4096 split experiments (BEM_SCAN_SPLIT=2..4)",
     r"ss2d_scan_bwd_kernel<1024, 4>": "general-L fallback of the scan backward (ragged planes); the shipped plane sizes use ss2d_scan_bwd_rows_kernel",
     r"gdmlp_x6_kernel<5, 3, 1, false>": "C = 80 form (x limbs of two halo blocks = 120 registers) at the 256-register budget of two workgroups per CU: 44 B",
     r"wgrad_kernel<3, 2":"checked separately: launch bound (256, 1) gives it 512 registers",

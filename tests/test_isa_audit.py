@@ -22,7 +22,14 @@ def test_isa_audit_clean():
         assert must in names, f"default-dispatched kernel {must} not found in the build"
     bad = ia.violations(ks)
     assert not bad, "\n".join(bad)
-    # the two scan launches of the L = 16384 row-major form are the ones VERDICT round 1 flagged (44 B of scratch): both must be clean
+    # the two scan launches of the L = 16384 row-major form are the ones VERDICT round 1 flagged (44 B of scratch): both must be clean;
+    # so must the L = 4096 form (12 B until the DPP steps of the lane scan became single instructions in round 3)
+    seen = 0
     for k in ks:
         if k["name"].startswith(("ss2d_scan_rows_kernel<1024, 4, 1, 3, 8, true, 0>", "ss2d_scan_rows_kernel<1024, 4, 1, 3, 8, true, 1>")):
             assert k["scratch"] == 0 and k["vgprs"] <= 64, (k["name"], k["scratch"], k["vgprs"])
+            seen += 1
+        if k["name"].startswith("ss2d_scan_rows_kernel<512, 2, 2, 5, 6, true, -1>"):
+            assert k["scratch"] == 0, (k["name"], k["scratch"])
+            seen += 1
+    assert seen == 3
