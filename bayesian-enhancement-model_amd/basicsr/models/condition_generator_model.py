@@ -1,5 +1,6 @@
 """ConditionGenerator (basicsr/models/condition_generator_model.py): Stage-I net + BNN conversion (:28-75), training settings and
 optimizer (:77-144), data feed (:146-174), the training step with the KL term (:176-218), checkpoints (:346-370)."""
+import os
 from collections import OrderedDict
 
 import torch
@@ -80,15 +81,31 @@ class ConditionGenerator(BaseModel):
 
     def optimize_parameters(self, current_iter):
         """zero_grad -> net_g(lq, mask) (mask dropped after the first scheduler period) -> l_total = 0.01 * l_kl / mini_batch + l_pix ->
-        backward -> clip_grad_norm_ -> AdamW (:176-218).  The train.png dumps every 100 iterations are host-side logging, not done here."""
-        self.optimizer_g.zero_grad()
+        backward -> clip_grad_norm_ -> AdamW (:176-218).  The train.png dumps every 100 iterations are host-side logging, not done here.
+
+        The step is ~2000 launches on 8x8 .. 2x2 planes, i.e. launch-bound: after one ordinary run per input geometry it is captured into a
+        HIP graph and replayed, with everything that differs between iterations read from device memory
+        (bem.train.StepState).  BEM_STAGE1_GRAPH=0, injected eps, a distributed run or an active launch profile keep the ordinary form."""
         if current_iter > self.opt["train"]["scheduler"]["periods"][0]:
             self.mask = None
+        from bem import ops
+        from bem.modules import _SAMPLE_CTX
+        skip = [self.net_g.mask_token] if self.mask is None else []
+        if (os.environ.get("BEM_STAGE1_GRAPH", "1") != "0" and _SAMPLE_CTX[0] is None and not self.opt.get("dist") and ops._PROF is None
+                and self.optimizer_g.graph_safe(skip)):
+            return self._optimize_graphed(current_iter, skip)
+        return self._step_body(current_iter, skip, None)
+
+    def _step_body(self, current_iter, skip, state):
+        from bem.modules import _SAMPLE_CTX, SampleCtx, sampling
+        self.optimizer_g.zero_grad()
         # the weight draws of iteration i come from Philox streams keyed by (manual_seed, rank, i): a resumed run draws what the
         # uninterrupted run would have drawn (the reference's resumed run restarts torch's generator instead)
-        from bem.modules import _SAMPLE_CTX, SampleCtx, sampling
-        ctx = _SAMPLE_CTX[0] or SampleCtx(1, None, seed=int(self.opt.get("manual_seed") or 0) & 0xFFFFFFFF, rank=int(self.opt.get("rank", 0)),
-                                          epoch=int(current_iter) & 0xFFFFFF)          # an enclosing context (injected eps) wins
+        seed, rank = int(self.opt.get("manual_seed") or 0) & 0xFFFFFFFF, int(self.opt.get("rank", 0))
+        if state is not None:
+            ctx = SampleCtx(1, None, seed=seed, rank=rank, epoch_dev=state.epoch_dev)
+        else:
+            ctx = _SAMPLE_CTX[0] or SampleCtx(1, None, seed=seed, rank=rank, epoch=int(current_iter) & 0xFFFFFF)   # an enclosing context (injected eps) wins
         with sampling(ctx):
             _, preds = self.net_g(self.lq.contiguous(), mask=self.mask)
         loss_dict = OrderedDict()
@@ -105,9 +122,46 @@ class ConditionGenerator(BaseModel):
         mgn = self.opt["train"].get("max_grad_norm")
         total_norm = self.optimizer_g.clip_grad_norm_(mgn if mgn else float("inf"))
         # a parameter outside this iteration's graph has .grad None in the reference and is skipped by AdamW: the mask token without a mask
-        self.optimizer_g.step(skip=[self.net_g.mask_token] if self.mask is None else ())
+        if state is not None:
+            self.optimizer_g.step_captured(state, skip=skip)
+            return loss_dict, total_norm
+        self.optimizer_g.step(skip=skip)
         self.log_dict = self.reduce_loss_dict(loss_dict)
         return total_norm
+
+    def _optimize_graphed(self, current_iter, skip):
+        """One captured step per input geometry: {"graph", "state", static inputs, the step's loss tensors}.  The first iteration with a
+        geometry runs the ordinary way (it is also the warm-up that leaves every lazily created buffer in place); the second records the
+        step -- recording launches nothing -- and is then replayed like all later ones."""
+        import bem.train as bt
+        key = (tuple(self.lq.shape), tuple(self.gt.shape), None if self.mask is None else tuple(self.mask.shape))
+        graphs = self.__dict__.setdefault("_graphs", {})
+        g = graphs.get(key)
+        if g is None:
+            graphs[key] = "warm"
+            return self._step_body(current_iter, skip, None)
+        if g == "warm":
+            g = {"state": bt.StepState(self.lq.device), "lq": self.lq.clone(), "gt": self.gt.clone(),
+                 "mask": None if self.mask is None else self.mask.clone(), "graph": torch.cuda.CUDAGraph()}
+            feed = self.lq, self.gt, self.mask
+            self.lq, self.gt, self.mask = g["lq"], g["gt"], g["mask"]
+            torch.cuda.synchronize()
+            bt.STEP_STATE[0] = g["state"]
+            try:
+                with torch.cuda.graph(g["graph"]):
+                    g["losses"], g["norm"] = self._step_body(current_iter, skip, g["state"])
+            finally:
+                bt.STEP_STATE[0] = None
+                self.lq, self.gt, self.mask = feed
+            graphs[key] = g
+        for dst, src in ((g["lq"], self.lq), (g["gt"], self.gt), (g["mask"], self.mask)):
+            if dst is not None and dst.data_ptr() != src.data_ptr():
+                dst.copy_(src)
+        g["state"].upload(current_iter)
+        g["graph"].replay()
+        g["state"].advance()
+        self.log_dict = self.reduce_loss_dict(g["losses"])
+        return g["norm"]
 
     # -- validation (:236-334) ----------------------------------------------------------------------------------------------------
     @torch.no_grad()

@@ -65,9 +65,15 @@ class SampleCtx:
 
     _epoch = 0      # process-wide forward counter: successive forwards never reuse a Philox stream
 
-    def __init__(self, nsets: int, eps: Optional[Dict[str, torch.Tensor]] = None, seed: int = 0, rank: int = 0, epoch: Optional[int] = None):
+    def __init__(self, nsets: int, eps: Optional[Dict[str, torch.Tensor]] = None, seed: int = 0, rank: int = 0, epoch: Optional[int] = None,
+                 epoch_dev: Optional[torch.Tensor] = None):
         self.nsets, self.eps, self.seed, self.rank = nsets, eps, seed, rank
         self.counter = 0
+        # epoch_dev: one int64 on the device holding ``epoch << 20``, added to the stream ids by the sampling kernels; the ids handed out
+        # here then carry epoch 0.  A captured step (HIP graph) replays with whatever epoch the host wrote there last.
+        self.epoch_dev = epoch_dev
+        if epoch_dev is not None:
+            epoch = 0
         if epoch is None:
             SampleCtx._epoch += 1
             epoch = SampleCtx._epoch
@@ -246,22 +252,31 @@ class _BayesBase(nn.Module):
         if self._sample_owner is step:
             return
         ctx = _SAMPLE_CTX[0]
-        d = min(self.decay, (1 + self.step) / (10 + self.step))
+        from .train import STEP_STATE
+        st = STEP_STATE[0]
+        decay = lambda: min(self.decay, (1 + self.step) / (10 + self.step))
+        d, d_dev = decay(), (st.slot(decay) if st is not None else None)       # a captured step reads the iteration's decay from HBM
         for kind in ("weight", "bias") if self.bias else ("weight",):
             mu, rho = getattr(self, f"mu_{kind}"), getattr(self, f"rho_{kind}")
-            ops.bnn_prior_ema_(getattr(self, f"prior_mu_{kind}"), getattr(self, f"prior_rho_{kind}"), mu.detach(), rho.detach(), d)
+            ops.bnn_prior_ema_(getattr(self, f"prior_mu_{kind}"), getattr(self, f"prior_rho_{kind}"), mu.detach(), rho.detach(), d, d_dev)
             if ctx.eps is not None:
                 e = ctx.eps[f"{self.module_path}.{kind}"].reshape((1,) + tuple(mu.shape)).contiguous()
             else:
-                e = ops.randn((1,) + tuple(mu.shape), mu.device, ctx.seed, ctx.next_stream())
+                e = ops.randn((1,) + tuple(mu.shape), mu.device, ctx.seed, ctx.next_stream(), ctx.epoch_dev)
             w = ops.bnn_sample(mu.detach(), rho.detach(), 1, e)[0]
             if kind == "weight":
                 self._ws, self._eps_w = w, e
             else:
                 self._bs, self._eps_b = w, e
-        self.step += 1
+        if st is None:
+            self.step += 1
+        else:
+            st.on_advance(self._count_step)           # recorded, not run: the counter moves when the captured step is replayed
         self._sample_owner = step
         step.leaves.append(self)
+
+    def _count_step(self):
+        self.step += 1
 
     def fold_sample_grads(self):
         """dmu += dw, drho += dw eps sigmoid(rho) for the sampled weight and bias of the finished backward pass, then drop the sample."""
@@ -299,12 +314,12 @@ class _BayesBase(nn.Module):
             # sigma = log1p(exp(rho)) once per weight version (one launch of the sampler with mu = 0, eps = 1), not once per sample
             rho = self.rho_weight
             sigma = self._cache.get("sigma", [rho], lambda: ops.bnn_sample(torch.zeros_like(rho), rho.detach(), 1, torch.ones_like(rho))[0])
-            w = ops.bnn_sample_packed(self.mu_weight.detach(), sigma, ns, packed_mk[0], packed_mk[1], ew, ctx.seed, ctx.next_stream(), sigma_given=True)
+            w = ops.bnn_sample_packed(self.mu_weight.detach(), sigma, ns, packed_mk[0], packed_mk[1], ew, ctx.seed, ctx.next_stream(), sigma_given=True, stream_add=ctx.epoch_dev)
         else:
-            w = ops.bnn_sample(self.mu_weight.detach(), self.rho_weight.detach(), ns, ew, ctx.seed, ctx.next_stream())
+            w = ops.bnn_sample(self.mu_weight.detach(), self.rho_weight.detach(), ns, ew, ctx.seed, ctx.next_stream(), ctx.epoch_dev)
         b = None
         if self.bias:
-            b = ops.bnn_sample(self.mu_bias.detach(), self.rho_bias.detach(), ns, eb, ctx.seed, ctx.next_stream())
+            b = ops.bnn_sample(self.mu_bias.detach(), self.rho_bias.detach(), ns, eb, ctx.seed, ctx.next_stream(), ctx.epoch_dev)
         return w, b, ns
 
 

@@ -49,6 +49,9 @@ P, I, I64, U64, F = c_void_p, c_int, c_int64, c_uint64, c_float
 # "every declared symbol is exported" CPU test checks against include/bem_hip.h.
 SIGNATURES = {
     "bem_selective_scan_fwd_f32": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, P],
+    "bem_selective_scan_fwd_in16": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P],
+    "bem_cast16_to_f32": [P, P, ctypes.c_int64, I, P],
+    "bem_cast_f32_to16": [P, P, ctypes.c_int64, I, P],
     "bem_selective_scan_bwd_ws_elems": [I, I, I, I],
     "bem_selective_scan_bwd_f32": [P] * 16 + [I, I, I, I, I, I, P],
     "bem_cross_scan_f32": [P, P, I, I, I, I, P],
@@ -62,8 +65,9 @@ SIGNATURES = {
     "bem_pw_gemm_x6_f32": [ctypes.POINTER(PwArgs), P],
     "bem_pack_pw_weight_x6": [P, P, I, I, I, P],
     "bem_pw_x6_packed_elems": [I, I],
-    "bem_bnn_sample_pack_x6": [P, P, P, P, I, I, I, U64, U64, I, P],
-    "bem_bnn_prior_ema_f32": [P, P, P, P, F, I64, P],
+    "bem_bnn_sample_pack_x6": [P, P, P, P, I, I, I, U64, U64, P, I, P],
+    "bem_store_words": [P, P, I, P],
+    "bem_bnn_prior_ema_f32": [P, P, P, P, F, P, I64, P],
     "bem_bnn_kl_f32": [P, P, P, P, I64, P, P],
     "bem_bnn_kl_bwd_f32": [P, P, P, P, I64, P, P, P, P],
     "bem_bnn_reparam_bwd_f32": [P, P, P, P, P, I64, P],
@@ -97,14 +101,14 @@ SIGNATURES = {
     "bem_bilinear_up_f32": [P, I64, P, I64, I, I, I, I, I, P],
     "bem_space_to_depth_f32": [P, P, I, I, I, I, P],
     "bem_pixel_shuffle2_f32": [P, P, I, I, I, I, P],
-    "bem_bnn_sample_f32": [P, P, P, P, I, I64, U64, U64, P],
+    "bem_bnn_sample_f32": [P, P, P, P, I, I64, U64, U64, P, P],
     "bem_select_best_f32": [P, P, P, P, P, I, I, I64, P],
     "bem_ssim_f32": [P, P, P, P, I, I, I, I, P],
     "bem_select_scores_f32": [P, P, P, F, I, P, P, P, P, I, I, I64, P],
     "bem_mc_mean_f32": [P, P, P, P, I, I, I, I, I, I, I, P],
     "bem_pad_reflect_f32": [P, P, I, I, I, I, I, P],
     "bem_resize_down_f32": [P, P, I, I, I, I, P],
-    "bem_randn_f32": [P, I64, U64, U64, P],
+    "bem_randn_f32": [P, I64, U64, U64, P, P],
     "bem_cond_postproc_f32": [P, P, P, P, I, I, I, I, F, P],
     "bem_plane_mean_f32": [P, P, I, I, I, I, I, P],
     "bem_candidate_finalize_f32": [P, P, P, P, P, I, I, I, I, I, I, I, P],
@@ -122,7 +126,7 @@ SIGNATURES = {
     "bem_conv_wgrad_f32": [P, P, I64, P, P, I, I, I, I, I, I, I, I, I, P],
     "bem_ss2d_scan_bwd_f32": [P] * 18 + [I, I, I, I, I64, I64, P],
     "bem_grad_sumsq_f32": [P, I64, P, P],
-    "bem_adamw_step_f32": [P, P, P, P, I64, F, F, F, F, F, I, F, P, P, P],
+    "bem_adamw_step_f32": [P, P, P, P, I64, F, F, F, F, F, I, F, P, P, P, P],
     "bem_last_error": [],
     "bem_abi_version": [],
 }

@@ -627,12 +627,20 @@ def pixel_shuffle2(x):
 
 
 # ------------------------------------------------------------------- Stage-I training pieces ----
-def bnn_prior_ema_(prior_mu, prior_rho, mu, rho, decay):
+def store_words(dst, host, n):
+    """dst[:n] (device, 32-bit elements) = host[:n] (CPU tensor of a 32-bit dtype), n <= 512, as the arguments of one launch."""
+    _chk(dst, "dst")
+    if host.is_cuda or host.element_size() != 4 or not host.is_contiguous() or n > host.numel() or n > dst.numel():
+        raise ValueError("store_words: a contiguous CPU tensor of 32-bit elements")
+    check(lib().bem_store_words(_p(dst), ctypes.c_void_p(host.data_ptr()), int(n), _stream()), "store_words")
+
+
+def bnn_prior_ema_(prior_mu, prior_rho, mu, rho, decay, decay_dev=None):
     for t, nm in ((prior_mu, "prior_mu"), (prior_rho, "prior_rho"), (mu, "mu"), (rho, "rho")):
         _chk(t, nm)
     if not (prior_mu.shape == prior_rho.shape == mu.shape == rho.shape):
         raise ValueError("bnn_prior_ema_: shapes differ")
-    check(lib().bem_bnn_prior_ema_f32(_p(prior_mu), _p(prior_rho), _p(mu), _p(rho), float(decay), mu.numel(), _stream()), "bnn_prior_ema")
+    check(lib().bem_bnn_prior_ema_f32(_p(prior_mu), _p(prior_rho), _p(mu), _p(rho), float(decay), _p(decay_dev), mu.numel(), _stream()), "bnn_prior_ema")
 
 
 def bnn_kl_(mu, rho, prior_mu, prior_rho, out):
@@ -719,25 +727,26 @@ def bilinear_up_bwd(dout, s):
 
 
 # --------------------------------------------------------------------------- Bayesian / MC ----
-def bnn_sample(mu, rho, nsets, eps=None, seed=0, stream_id=0):
-    """w[s] = mu + log1p(exp(rho)) * eps[s];  eps None -> Philox N(0,1) keyed by (seed, stream_id)."""
+def bnn_sample(mu, rho, nsets, eps=None, seed=0, stream_id=0, stream_add=None):
+    """w[s] = mu + log1p(exp(rho)) * eps[s];  eps None -> Philox N(0,1) keyed by (seed, stream_id [+ stream_add[0], a one-element int64
+    device tensor read by the kernel: the per-iteration part of the id of a graph-captured step])."""
     _chk(mu, "mu"); _chk(rho, "rho"); _chk(eps, "eps", optional=True)
     n = mu.numel()
     if rho.numel() != n or (eps is not None and eps.numel() != nsets * n):
         raise ValueError("bnn_sample: shapes")
     out = torch.empty((nsets,) + tuple(mu.shape), device=mu.device, dtype=mu.dtype)
-    check(lib().bem_bnn_sample_f32(_p(mu), _p(rho), _p(eps), _p(out), nsets, n, seed, stream_id, _stream()), "bnn_sample")
+    check(lib().bem_bnn_sample_f32(_p(mu), _p(rho), _p(eps), _p(out), nsets, n, seed, stream_id, _p(stream_add), _stream()), "bnn_sample")
     return out
 
 
-def bnn_sample_packed(mu, rho, nsets, M, K, eps=None, seed=0, stream_id=0, sigma_given=False):
+def bnn_sample_packed(mu, rho, nsets, M, K, eps=None, seed=0, stream_id=0, sigma_given=False, stream_add=None):
     """bnn_sample + pack_pw_weight(x6) in one kernel: (nsets, packed(M, K)) GEMM weights of a Bayesian 1x1 layer.
     sigma_given: ``rho`` already holds sigma = log1p(exp(rho)) (it does not depend on the sample)."""
     _chk(mu, "mu"); _chk(rho, "rho"); _chk(eps, "eps", optional=True)
     if mu.numel() != M * K or rho.numel() != M * K or (eps is not None and eps.numel() != nsets * M * K):
         raise ValueError("bnn_sample_packed: shapes")
     out = torch.empty(nsets, packed_elems(M, K, True), device=mu.device, dtype=mu.dtype)
-    check(lib().bem_bnn_sample_pack_x6(_p(mu), _p(rho), _p(eps), _p(out), nsets, M, K, seed, stream_id, int(bool(sigma_given)), _stream()), "bnn_sample_pack_x6")
+    check(lib().bem_bnn_sample_pack_x6(_p(mu), _p(rho), _p(eps), _p(out), nsets, M, K, seed, stream_id, _p(stream_add), int(bool(sigma_given)), _stream()), "bnn_sample_pack_x6")
     out._bem_mk = (M, K)
     return out
 
@@ -762,9 +771,9 @@ def resize_down(x, s):
     return out
 
 
-def randn(shape, device, seed=0, stream_id=0):
+def randn(shape, device, seed=0, stream_id=0, stream_add=None):
     out = torch.empty(shape, device=device, dtype=torch.float32)
-    check(lib().bem_randn_f32(_p(out), out.numel(), seed, stream_id, _stream()), "randn")
+    check(lib().bem_randn_f32(_p(out), out.numel(), seed, stream_id, _p(stream_add), _stream()), "randn")
     return out
 
 
@@ -1073,7 +1082,9 @@ def grad_sumsq(g, acc):
     return acc
 
 
-def adamw_step_(p, g, m, v, lr, betas, eps, weight_decay, step, max_norm=0.0, sumsq=None, norm_out=None):
+def adamw_step_(p, g, m, v, lr, betas, eps, weight_decay, step, max_norm=0.0, sumsq=None, norm_out=None, hyper=None):
+    """hyper: optional device tensor [lr, 1 - beta1^t, sqrt(1 - beta2^t)] read by the kernel in place of ``lr`` / ``step``."""
+    _chk(hyper, "hyper", optional=True)
     for n, t in (("p", p), ("g", g), ("m", m), ("v", v)):
         _chk(t, n)
     _chk(sumsq, "sumsq", dtype=torch.float64, optional=True); _chk(norm_out, "norm_out", optional=True)
@@ -1081,7 +1092,7 @@ def adamw_step_(p, g, m, v, lr, betas, eps, weight_decay, step, max_norm=0.0, su
     if g.numel() != n or m.numel() != n or v.numel() != n:
         raise ValueError("adamw_step: buffer sizes differ")
     check(lib().bem_adamw_step_f32(_p(p), _p(g), _p(m), _p(v), n, float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
-                                   int(step), float(max_norm), _p(sumsq), _p(norm_out), _stream()), "adamw_step")
+                                   int(step), float(max_norm), _p(sumsq), _p(norm_out), _p(hyper), _stream()), "adamw_step")
 
 
 # --------------------------------------------------------------------------- launch timing ----

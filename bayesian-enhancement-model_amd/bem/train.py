@@ -22,6 +22,51 @@ def _align4(n: int) -> int:
     return (n + 3) // 4 * 4
 
 
+class StepState:
+    """Per-iteration scalars of a graph-captured training step, resident in HBM.
+
+    A HIP graph replays its kernels with the arguments they were captured with, so everything that changes from one iteration to the
+    next -- the Philox epoch of the weight draws, the learning rate and Adam's bias corrections, each Bayesian leaf's EMA decay --
+    is read by the kernels from this buffer instead (``stream_add`` / ``hyper`` / ``decay_dev`` of the C ABI).  ``slot(fn, k)`` hands
+    out k floats whose values ``fn()`` supplies before every run; ``upload`` evaluates them and sends all words with ONE launch
+    (bem_store_words); ``advance`` runs the host-side bookkeeping of the step (counters the eager path bumps inline) after it."""
+
+    WORDS = 512
+
+    def __init__(self, device):
+        self.dev = torch.zeros(self.WORDS, device=device, dtype=torch.float32)
+        self.host = torch.zeros(self.WORDS, dtype=torch.float32)
+        self.epoch_dev = self.dev[:2].view(torch.int64)            # words 0..1: [epoch] << 20 (SampleCtx.next_stream's epoch field)
+        self._host_epoch = self.host[:2].view(torch.int64)
+        self.n = 2
+        self._fns, self._advance = [], []
+
+    def slot(self, fn, k: int = 1):
+        if self.n + k > self.WORDS:
+            raise RuntimeError("StepState: out of slots")
+        view = self.dev[self.n:self.n + k]
+        self._fns.append((self.n, k, fn))
+        self.n += k
+        return view
+
+    def on_advance(self, fn):
+        self._advance.append(fn)
+
+    def upload(self, epoch: int):
+        self._host_epoch[0] = (int(epoch) & 0xFFFFFF) << 20
+        for off, k, fn in self._fns:
+            v = fn()
+            self.host[off:off + k] = torch.as_tensor(v, dtype=torch.float32).reshape(k)
+        ops.store_words(self.dev, self.host, self.n)
+
+    def advance(self):
+        for fn in self._advance:
+            fn()
+
+
+STEP_STATE = [None]        # set while a step is being captured: leaves and the optimizer take their per-iteration scalars from it
+
+
 class BemAdamW(torch.optim.Optimizer):
     def __init__(self, params: Iterable, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, **ignored):
         defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
@@ -110,6 +155,47 @@ class BemAdamW(torch.optim.Optimizer):
                     return tuple(f[k][off:off + n] for k in ("p", "g", "m", "v")), group
                 off += _align4(n)
         raise KeyError("BemAdamW: parameter is not in any group")
+
+    def graph_safe(self, skip=()):
+        """True when step(skip) is the single fused launch per group (no parameter that lags behind the shared count and needs its own
+        bias corrections): the form a captured step can replay."""
+        skip = list(skip)
+        return not any(lag and not any(p is q for q in skip) for p, lag in self._lag.items())
+
+    def _host_advance(self, skip):
+        self._steps += 1
+        for f in self._flat:
+            if f is not None:
+                for p in f["params"]:
+                    self.state[p]["step"] += 1
+        for p in skip:
+            self.state[p]["step"] -= 1
+            self._lag[p] = self._lag.get(p, 0) + 1
+        ops.bump_weight_epoch()
+
+    @torch.no_grad()
+    def step_captured(self, state: StepState, skip=()):
+        """step(skip) recorded for replay: learning rate and bias corrections come from ``state`` slots (filled from the host's group['lr']
+        and step count before each run), the counters advance in ``state.advance()`` after each run instead of here."""
+        skip = list(skip)
+        if not self.graph_safe(skip):
+            raise RuntimeError("BemAdamW.step_captured: a lagging parameter needs its own step count (run step())")
+        keep = [(p, p.detach().clone(), self.state[p]["exp_avg"].clone(), self.state[p]["exp_avg_sq"].clone()) for p in skip]
+        for group, f in zip(self.param_groups, self._flat):
+            if f is None:
+                continue
+            b1, b2 = group["betas"]
+
+            def hyper(group=group, b1=b1, b2=b2):
+                t = self._steps + 1
+                return [float(group["lr"]), float(1.0 - b1 ** t), float((1.0 - b2 ** t) ** 0.5)]
+            ops.adamw_step_(f["p"], f["g"], f["m"], f["v"], group["lr"], group["betas"], group["eps"], group["weight_decay"], 0,
+                            max_norm=self._max_norm, sumsq=self._sumsq if self._max_norm > 0 else None, norm_out=self._norm,
+                            hyper=state.slot(hyper, 3))
+        for p, val, m, v in keep:
+            p.copy_(val); self.state[p]["exp_avg"].copy_(m); self.state[p]["exp_avg_sq"].copy_(v)
+        self._max_norm = 0.0
+        state.on_advance(lambda: self._host_advance(skip))
 
     @torch.no_grad()
     def step(self, closure=None, skip=()):

@@ -506,7 +506,8 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 // gradient is written back, as clip_grad_norm_ does in place.  max_norm <= 0: no clipping.
 __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
                              float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt, float max_norm,
-                             const double* __restrict__ sumsq, float* __restrict__ norm_out) {
+                             const double* __restrict__ sumsq, float* __restrict__ norm_out, const float* __restrict__ hyper) {
+    if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2_sqrt = hyper[2]; }     // per-iteration values of a captured step, kept in HBM
     float coef = 1.f;
     if (max_norm > 0.f) {
         const float tn = (float)sqrt(sumsq[0]);
@@ -647,11 +648,11 @@ extern "C" int bem_grad_sumsq_f32(const float* g, int64_t n, double* acc, void* 
 }
 
 extern "C" int bem_adamw_step_f32(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                                  float weight_decay, int step, float max_norm, const double* sumsq, float* norm_out, void* stream) {
-    BEM_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adamw_step: bad arguments");
+                                  float weight_decay, int step, float max_norm, const double* sumsq, float* norm_out, const float* hyper, void* stream) {
+    BEM_REQUIRE(p && g && m && v && n > 0 && (step >= 1 || hyper), "adamw_step: bad arguments");
     BEM_REQUIRE(max_norm <= 0.f || sumsq, "adamw_step: clipping needs the sum of squares from bem_grad_sumsq_f32");
-    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const double bc1 = 1.0 - pow((double)beta1, step > 0 ? step : 1), bc2 = 1.0 - pow((double)beta2, step > 0 ? step : 1);
     adamw_kernel<<<GRID1D(n), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2),
-                                                          max_norm, sumsq, norm_out);
+                                                          max_norm, sumsq, norm_out, hyper);
     return bem_check_launch("adamw_step");
 }

@@ -420,18 +420,23 @@ __global__ void resize_down_kernel(const float* __restrict__ x, float* __restric
 }
 
 // ---------------------------------------------------------------- Bayesian sampling ----------
-__global__ void randn_kernel(float* __restrict__ out, int64_t total, uint64_t seed, uint64_t stream_id) {
+// stream_add (all three samplers): an optional device-resident addend of the Philox stream id -- the per-iteration part of the id
+// ([forward epoch] << 20, see SampleCtx.next_stream) kept in HBM so that a captured HIP graph of the step draws fresh numbers on
+// every replay; NULL = the id is complete as passed.
+__global__ void randn_kernel(float* __restrict__ out, int64_t total, uint64_t seed, uint64_t stream_id, const uint64_t* __restrict__ stream_add) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (stream_add) stream_id += stream_add[0];
     if (i < total) out[i] = philox_normal(i, seed, stream_id);
 }
 
 // one thread = four consecutive elements = one Philox counter block
 __global__ void bnn_sample_kernel(const float* __restrict__ mu, const float* __restrict__ rho,
                                   const float* __restrict__ eps_in, float* __restrict__ out, int64_t n, int64_t total,
-                                  uint64_t seed, uint64_t stream_id) {
+                                  uint64_t seed, uint64_t stream_id, const uint64_t* __restrict__ stream_add) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t i0 = 4 * j;
     if (i0 >= total) return;
+    if (stream_add) stream_id += stream_add[0];
     float z[4] = {0.f, 0.f, 0.f, 0.f};
     if (!eps_in) philox_normal4(j, seed, stream_id, z);
 #pragma unroll
@@ -845,12 +850,12 @@ extern "C" int bem_pixel_shuffle2_f32(const float* x, float* out, int B, int C, 
 }
 
 extern "C" int bem_bnn_sample_f32(const float* mu, const float* rho, const float* eps_in, float* out, int nsets,
-                                  int64_t n, uint64_t seed, uint64_t stream_id, void* stream) {
+                                  int64_t n, uint64_t seed, uint64_t stream_id, const uint64_t* stream_add, void* stream) {
     BEM_REQUIRE(mu && rho && out, "bnn_sample: null tensor");
     BEM_REQUIRE(nsets >= 0 && n >= 0, "bnn_sample: bad shape");
     const int64_t total = (int64_t)nsets * n;
     if (total == 0) return BEM_OK;
-    bnn_sample_kernel<<<GRID1D(cdiv64(total, 4)), 256, 0, (hipStream_t)stream>>>(mu, rho, eps_in, out, n, total, seed, stream_id);
+    bnn_sample_kernel<<<GRID1D(cdiv64(total, 4)), 256, 0, (hipStream_t)stream>>>(mu, rho, eps_in, out, n, total, seed, stream_id, stream_add);
     return bem_check_launch("bnn_sample");
 }
 
@@ -905,10 +910,10 @@ extern "C" int bem_resize_down_f32(const float* x, float* out, int P, int Hp, in
     return bem_check_launch("resize_down");
 }
 
-extern "C" int bem_randn_f32(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream) {
+extern "C" int bem_randn_f32(float* out, int64_t n, uint64_t seed, uint64_t stream_id, const uint64_t* stream_add, void* stream) {
     BEM_REQUIRE(out && n >= 0, "randn: bad arguments");
     if (n == 0) return BEM_OK;
-    randn_kernel<<<GRID1D(n), 256, 0, (hipStream_t)stream>>>(out, n, seed, stream_id);
+    randn_kernel<<<GRID1D(n), 256, 0, (hipStream_t)stream>>>(out, n, seed, stream_id, stream_add);
     return bem_check_launch("randn");
 }
 
@@ -974,4 +979,41 @@ extern "C" int bem_mc_mean_f32(const float* pred, const float* target, float* ou
         mc_rescale_kernel<<<GRID1D(total), 256, 0, s>>>(out, ws, (int64_t)3 * h * w, total);
     }
     return bem_check_launch("mc_mean");
+}
+
+// ------------------------------------------------------------------------------------------------
+// 16-bit <-> float32 casts of the operator seam's backward (selective_scan_cuda_oflex.bwd with f16 / bf16 inputs): dtype 1 = float16,
+// 2 = bfloat16 (round to nearest even on the way down, like torch's .to()).
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ void cast16_to_f32_kernel(const uint16_t* __restrict__ src, float* __restrict__ dst, int64_t n, int dtype) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint16_t b = src[i];
+    dst[i] = dtype == 1 ? (float)__builtin_bit_cast(_Float16, b) : __builtin_bit_cast(float, (uint32_t)b << 16);
+}
+__global__ void cast_f32_to16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int64_t n, int dtype) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = src[i];
+    if (dtype == 1) {
+        dst[i] = __builtin_bit_cast(uint16_t, (_Float16)v);
+    } else {
+        const uint32_t u = __builtin_bit_cast(uint32_t, v);
+        dst[i] = (v != v) ? (uint16_t)0x7fc0 : (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    }
+}
+}  // namespace
+
+extern "C" int bem_cast16_to_f32(const void* src, float* dst, int64_t n, int dtype, void* stream) {
+    BEM_REQUIRE(src && dst && n >= 0 && (dtype == 1 || dtype == 2), "cast16_to_f32: bad arguments");
+    if (n == 0) return BEM_OK;
+    cast16_to_f32_kernel<<<(unsigned)cdiv64(n, 256), 256, 0, (hipStream_t)stream>>>((const uint16_t*)src, dst, n, dtype);
+    return bem_check_launch("cast16_to_f32");
+}
+extern "C" int bem_cast_f32_to16(const float* src, void* dst, int64_t n, int dtype, void* stream) {
+    BEM_REQUIRE(src && dst && n >= 0 && (dtype == 1 || dtype == 2), "cast_f32_to16: bad arguments");
+    if (n == 0) return BEM_OK;
+    cast_f32_to16_kernel<<<(unsigned)cdiv64(n, 256), 256, 0, (hipStream_t)stream>>>(src, (uint16_t*)dst, n, dtype);
+    return bem_check_launch("cast_f32_to16");
 }

@@ -547,9 +547,10 @@ __global__ void pack_x6_kernel(const float* __restrict__ W, u32x4* __restrict__ 
 // and stored like pack_x6_kernel does -- the natural-order copy (one write + one read per weight and sample) is skipped.
 __global__ void sample_pack_x6_kernel(const float* __restrict__ mu, const float* __restrict__ rho, const float* __restrict__ eps_in,
                                       u32x4* __restrict__ Wp, int M, int K, int MT, int KB, int64_t total, uint64_t seed, uint64_t stream_id,
-                                      int sigma_given) {
+                                      const uint64_t* __restrict__ stream_add, int sigma_given) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
+    if (stream_add) stream_id += stream_add[0];                          // device-resident part of the id (see randn_kernel)
     const int lane = (int)(i & 63);
     const int64_t blk = i >> 6;
     const int kb = (int)(blk % KB), mt = (int)((blk / KB) % MT);
@@ -586,7 +587,7 @@ __global__ void sample_pack_x6_kernel(const float* __restrict__ mu, const float*
 }  // namespace
 
 extern "C" int bem_bnn_sample_pack_x6(const float* mu, const float* rho, const float* eps_in, float* Wp, int nsets, int M, int K,
-                                      uint64_t seed, uint64_t stream_id, int sigma_given, void* stream) {
+                                      uint64_t seed, uint64_t stream_id, const uint64_t* stream_add, int sigma_given, void* stream) {
     BEM_REQUIRE(mu && rho && Wp, "bnn_sample_pack_x6: null tensor");
     BEM_REQUIRE(nsets >= 0 && M > 0 && K > 0, "bnn_sample_pack_x6: bad shape");
     BEM_REQUIRE(((uintptr_t)Wp & 15) == 0, "bnn_sample_pack_x6: output must be 16-byte aligned");
@@ -594,7 +595,7 @@ extern "C" int bem_bnn_sample_pack_x6(const float* mu, const float* rho, const f
     const int MT = cdiv(M, 32), KB = cdiv(K, 16);
     const int64_t total = (int64_t)nsets * MT * KB * 64;
     sample_pack_x6_kernel<<<(unsigned)cdiv64(total, 256), 256, 0, (hipStream_t)stream>>>(mu, rho, eps_in, reinterpret_cast<u32x4*>(Wp), M, K, MT, KB,
-                                                                                       total, seed, stream_id, sigma_given);
+                                                                                       total, seed, stream_id, stream_add, sigma_given);
     return bem_check_launch("bnn_sample_pack_x6");
 }
 

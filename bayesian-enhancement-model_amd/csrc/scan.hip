@@ -16,10 +16,10 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // General selective scan (any dstate, groups): one workgroup per (batch, channel) row.
 // ------------------------------------------------------------------------------------------------
-template <int NT, int E>
+template <int NT, int E, typename TI>
 __global__ __launch_bounds__(NT) void selective_scan_fwd_kernel(
-    const float* __restrict__ u, const float* __restrict__ delta, const float* __restrict__ A,
-    const float* __restrict__ Bm, const float* __restrict__ Cm, const float* __restrict__ D,
+    const TI* __restrict__ u, const TI* __restrict__ delta, const float* __restrict__ A,
+    const TI* __restrict__ Bm, const TI* __restrict__ Cm, const float* __restrict__ D,
     const float* __restrict__ dbias, float* __restrict__ out, int dim, int L, int dstate, int ngroups,
     int softplus) {
     __shared__ float agg[2 * (NT / BEM_WAVE)];
@@ -27,8 +27,8 @@ __global__ __launch_bounds__(NT) void selective_scan_fwd_kernel(
     const int d = blockIdx.x, b = blockIdx.y;
     const int g = d / (dim / ngroups);
     const int64_t row = ((int64_t)b * dim + d) * L;
-    const float* ur = u + row;
-    const float* dr = delta + row;
+    const TI* ur = u + row;
+    const TI* dr = delta + row;
     float* yr = out + row;
     const float bias = dbias ? dbias[d] : 0.f;
     const float Dd = D ? D[d] : 0.f;
@@ -741,25 +741,46 @@ __global__ void cross_merge_kernel(const float* __restrict__ ys, float* __restri
 
 }  // namespace
 
-extern "C" int bem_selective_scan_fwd_f32(const float* u, const float* delta, const float* A, const float* Bm,
-                                          const float* Cm, const float* D, const float* delta_bias, float* out,
-                                          int batch, int dim, int L, int dstate, int ngroups, int delta_softplus,
-                                          void* stream) {
+template <typename TI>
+static int selective_scan_fwd_launch(const TI* u, const TI* delta, const float* A, const TI* Bm, const TI* Cm, const float* D, const float* delta_bias,
+                                     float* out, int batch, int dim, int L, int dstate, int ngroups, int delta_softplus, void* stream) {
     BEM_REQUIRE(u && delta && A && Bm && Cm && out, "selective_scan_fwd: null tensor");
     BEM_REQUIRE(batch >= 0 && dim > 0 && L >= 0, "selective_scan_fwd: bad shape (%d,%d,%d)", batch, dim, L);
     BEM_REQUIRE(dstate >= 1 && dstate <= 256, "selective_scan_fwd: dstate %d not in [1,256]", dstate);
     BEM_REQUIRE(ngroups >= 1 && dim % ngroups == 0, "selective_scan_fwd: dim %d %% ngroups %d != 0", dim, ngroups);
     BEM_REQUIRE(batch <= 65535, "selective_scan_fwd: batch %d > 65535", batch);
+    BEM_REQUIRE(sizeof(TI) == 4 || L % 4 != 0 || (((uintptr_t)u | (uintptr_t)delta | (uintptr_t)Bm | (uintptr_t)Cm) & 7) == 0,
+                "selective_scan_fwd: 16-bit inputs must be 8-byte aligned");
     if (batch == 0 || L == 0) return BEM_OK;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(dim, batch);
     if (L <= 256)
-        selective_scan_fwd_kernel<64, 4><<<grid, 64, 0, s>>>(u, delta, A, Bm, Cm, D, delta_bias, out, dim, L, dstate, ngroups, delta_softplus);
+        selective_scan_fwd_kernel<64, 4, TI><<<grid, 64, 0, s>>>(u, delta, A, Bm, Cm, D, delta_bias, out, dim, L, dstate, ngroups, delta_softplus);
     else if (L <= 1024)
-        selective_scan_fwd_kernel<128, 8><<<grid, 128, 0, s>>>(u, delta, A, Bm, Cm, D, delta_bias, out, dim, L, dstate, ngroups, delta_softplus);
+        selective_scan_fwd_kernel<128, 8, TI><<<grid, 128, 0, s>>>(u, delta, A, Bm, Cm, D, delta_bias, out, dim, L, dstate, ngroups, delta_softplus);
     else
-        selective_scan_fwd_kernel<256, 8><<<grid, 256, 0, s>>>(u, delta, A, Bm, Cm, D, delta_bias, out, dim, L, dstate, ngroups, delta_softplus);
+        selective_scan_fwd_kernel<256, 8, TI><<<grid, 256, 0, s>>>(u, delta, A, Bm, Cm, D, delta_bias, out, dim, L, dstate, ngroups, delta_softplus);
     return bem_check_launch("selective_scan_fwd");
+}
+
+extern "C" int bem_selective_scan_fwd_f32(const float* u, const float* delta, const float* A, const float* Bm,
+                                          const float* Cm, const float* D, const float* delta_bias, float* out,
+                                          int batch, int dim, int L, int dstate, int ngroups, int delta_softplus,
+                                          void* stream) {
+    return selective_scan_fwd_launch<float>(u, delta, A, Bm, Cm, D, delta_bias, out, batch, dim, L, dstate, ngroups, delta_softplus, stream);
+}
+
+// u, delta, B, C in float16 (in_dtype 1) or bfloat16 (2), read as they are; A, D, delta_bias and the output float32 (the reference's
+// out_float = true form; selective_scan_oflex.cpp:166-216)
+extern "C" int bem_selective_scan_fwd_in16(const void* u, const void* delta, const float* A, const void* Bm, const void* Cm, const float* D,
+                                           const float* delta_bias, float* out, int in_dtype, int batch, int dim, int L, int dstate, int ngroups,
+                                           int delta_softplus, void* stream) {
+    BEM_REQUIRE(in_dtype == 1 || in_dtype == 2, "selective_scan_fwd_in16: in_dtype %d (1 = float16, 2 = bfloat16)", in_dtype);
+    if (in_dtype == 1)
+        return selective_scan_fwd_launch<bem_half_t>((const bem_half_t*)u, (const bem_half_t*)delta, A, (const bem_half_t*)Bm, (const bem_half_t*)Cm, D,
+                                                     delta_bias, out, batch, dim, L, dstate, ngroups, delta_softplus, stream);
+    return selective_scan_fwd_launch<bem_bf16_t>((const bem_bf16_t*)u, (const bem_bf16_t*)delta, A, (const bem_bf16_t*)Bm, (const bem_bf16_t*)Cm, D,
+                                                 delta_bias, out, batch, dim, L, dstate, ngroups, delta_softplus, stream);
 }
 
 extern "C" int bem_ss2d_scan_strided_f32(const float* x0, const float* x1, const float* xd0, const float* xd1,

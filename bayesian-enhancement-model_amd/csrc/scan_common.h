@@ -91,6 +91,26 @@ __device__ __forceinline__ void load_row(const float* __restrict__ p, int64_t t0
         for (int i = 0; i < E; ++i) v[i] = (t0 + i < L) ? p[t0 + i] : 0.f;
     }
 }
+// 16-bit inputs of the operator seam (selective_scan_oflex.cpp:166-216 takes f16 / bf16 u, delta, B, C): the same row access, 2 bytes per
+// element, converted in registers -- no f32 copy of the tensor is made.
+struct bem_half_t { uint16_t b; };
+struct bem_bf16_t { uint16_t b; };
+__device__ __forceinline__ float bem_to_f32(bem_half_t h) { return (float)__builtin_bit_cast(_Float16, h.b); }
+__device__ __forceinline__ float bem_to_f32(bem_bf16_t h) { return __builtin_bit_cast(float, (uint32_t)h.b << 16); }
+template <int E, typename T16>
+__device__ __forceinline__ void load_row(const T16* __restrict__ p, int64_t t0, int L, bool vec, float (&v)[E]) {
+    if (vec && t0 + E <= L) {                       // vec: L % 4 == 0 and the tensor 8-byte aligned -> 8-byte pieces of 4 elements
+#pragma unroll
+        for (int i = 0; i < E; i += 4) {
+            const uint2 q = *reinterpret_cast<const uint2*>(p + t0 + i);
+            v[i] = bem_to_f32(T16{(uint16_t)(q.x & 0xffffu)}); v[i + 1] = bem_to_f32(T16{(uint16_t)(q.x >> 16)});
+            v[i + 2] = bem_to_f32(T16{(uint16_t)(q.y & 0xffffu)}); v[i + 3] = bem_to_f32(T16{(uint16_t)(q.y >> 16)});
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < E; ++i) v[i] = (t0 + i < L) ? bem_to_f32(p[t0 + i]) : 0.f;
+    }
+}
 template <int E>
 __device__ __forceinline__ void store_row(float* __restrict__ p, int64_t t0, int L, bool vec, const float (&v)[E]) {
     if (vec && t0 + E <= L) {

@@ -8,6 +8,8 @@
 // Stage-I planes are H/16 x W/16 (8 x 8 at the shipped gt_size 128): every kernel here is launch-latency sized, so they are plain
 // one-thread-per-element kernels with block reductions + one atomic per block where a sum is needed.
 #include "bem_common.h"
+#include <cstring>
+#define BEM_STEP_WORDS_MAX 512
 
 namespace {
 
@@ -27,9 +29,10 @@ __device__ __forceinline__ float softplus_ref(float r) { return log1pf(expf(r));
 __device__ __forceinline__ float sigmoid_ref(float r) { return 1.f / (1.f + expf(-r)); }
 
 __global__ void prior_ema_kernel(float* __restrict__ pmu, float* __restrict__ prho, const float* __restrict__ mu,
-                                 const float* __restrict__ rho, float decay, int64_t n) {
+                                 const float* __restrict__ rho, float decay, const float* __restrict__ decay_dev, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
     if (i >= n) return;
+    if (decay_dev) decay = decay_dev[0];                 // the iteration's decay read from HBM (captured step)
     pmu[i] = decay * pmu[i] + (1.f - decay) * mu[i];
     prho[i] = decay * prho[i] + (1.f - decay) * rho[i];
 }
@@ -158,12 +161,31 @@ inline int grid_for(int64_t n, int cap = 1024) { return (int)std::min<int64_t>((
 
 }  // namespace
 
-extern "C" int bem_bnn_prior_ema_f32(float* prior_mu, float* prior_rho, const float* mu, const float* rho, float decay, int64_t n,
-                                     void* stream) {
+// The per-iteration scalars of a captured step (Philox epoch, learning rate, Adam bias corrections, EMA decays) travel as kernel
+// ARGUMENTS of this one launch into their device-resident slots: stream-ordered like every other launch, no pinned staging buffer
+// whose reuse would have to be fenced.
+namespace {
+struct step_words { uint32_t w[BEM_STEP_WORDS_MAX]; };
+__global__ void store_words_kernel(uint32_t* __restrict__ dst, step_words v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = v.w[i];
+}
+}  // namespace
+
+extern "C" int bem_store_words(void* dst, const void* host_words, int n, void* stream) {
+    BEM_REQUIRE(dst && host_words && n > 0 && n <= BEM_STEP_WORDS_MAX, "store_words: 1..%d 32-bit words", BEM_STEP_WORDS_MAX);
+    step_words v;
+    memcpy(v.w, host_words, sizeof(uint32_t) * (size_t)n);
+    store_words_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>((uint32_t*)dst, v, n);
+    return bem_check_launch("store_words");
+}
+
+extern "C" int bem_bnn_prior_ema_f32(float* prior_mu, float* prior_rho, const float* mu, const float* rho, float decay,
+                                     const float* decay_dev, int64_t n, void* stream) {
     BEM_REQUIRE(prior_mu && prior_rho && mu && rho, "bnn_prior_ema: null tensor");
     BEM_REQUIRE(n >= 0 && decay >= 0.f && decay <= 1.f, "bnn_prior_ema: bad size / decay");
     if (n == 0) return BEM_OK;
-    prior_ema_kernel<<<(unsigned)((n + NT - 1) / NT), NT, 0, (hipStream_t)stream>>>(prior_mu, prior_rho, mu, rho, decay, n);
+    prior_ema_kernel<<<(unsigned)((n + NT - 1) / NT), NT, 0, (hipStream_t)stream>>>(prior_mu, prior_rho, mu, rho, decay, decay_dev, n);
     return bem_check_launch("bnn_prior_ema");
 }
 

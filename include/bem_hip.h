@@ -42,6 +42,18 @@ int bem_selective_scan_fwd_f32(const float* u, const float* delta, const float* 
                                int batch, int dim, int L, int dstate, int ngroups, int delta_softplus,
                                void* stream);
 
+/* The same call with u, delta, Bm, Cm in float16 (in_dtype 1) or bfloat16 (in_dtype 2), read as they are (8-byte aligned when
+ * L % 4 == 0); A, D, delta_bias and out float32 -- the extension's input_t = at::Half / at::BFloat16 instantiations with
+ * out_float = true (selective_scan_oflex.cpp:166-216; csms6s.py:85 passes oflex). */
+int bem_selective_scan_fwd_in16(const void* u, const void* delta, const float* A, const void* Bm, const void* Cm, const float* D,
+                                const float* delta_bias, float* out, int in_dtype, int batch, int dim, int L, int dstate,
+                                int ngroups, int delta_softplus, void* stream);
+
+/* Element casts for the 16-bit forms of the seam's backward (the extension converts inside its kernels, selective_scan_bwd_kernel_oflex.cuh:
+ * 108-140; here the f32 kernel runs between two casts): dtype 1 = float16, 2 = bfloat16, round to nearest even, n elements. */
+int bem_cast16_to_f32(const void* src, float* dst, int64_t n, int dtype, void* stream);
+int bem_cast_f32_to16(const float* src, void* dst, int64_t n, int dtype, void* stream);
+
 /* Replaces selective_scan_cuda_oflex.bwd (selective_scan_oflex.cpp:245-358, kernel selective_scan_bwd_kernel_oflex.cuh:73-289),
  * f32.  dout, du, ddelta: (batch, dim, L); dA (dim, dstate); dB, dC (batch, ngroups, dstate, L) f32; dD, ddelta_bias (dim)
  * or NULL exactly when D / delta_bias are NULL.  ws: scratch of bem_selective_scan_bwd_ws_elems(...) floats (the role of
@@ -132,7 +144,8 @@ int64_t bem_pw_x6_packed_elems(int M, int K);
  * sets w = mu + log1p(exp(rho)) * eps written straight in x6 operand order; eps (nsets, M, K) injected or NULL = the
  * sampler's Philox draws for (seed, stream_id) -- identical values to sampling first and packing afterwards. */
 int bem_bnn_sample_pack_x6(const float* mu, const float* rho, const float* eps, float* Wp, int nsets, int M, int K,
-                           uint64_t seed, uint64_t stream_id, int sigma_given, void* stream);   /* sigma_given: rho already holds log1p(exp(rho)) */
+                           uint64_t seed, uint64_t stream_id, const uint64_t* stream_add, int sigma_given,
+                           void* stream);   /* sigma_given: rho already holds log1p(exp(rho)); stream_add: see bem_bnn_sample_f32 */
 
 /* ---------------------------------------------------------------------------------------------
  * Convolutions.
@@ -233,15 +246,18 @@ int bem_pixel_shuffle2_f32(const float* x, float* out, int B, int C, int H, int 
  * Bayesian sampling + Monte-Carlo loop pieces (basicsr/bayesian/conv.py:106-114, eval.py:199-264).
  * ------------------------------------------------------------------------------------------- */
 /* out[s][i] = mu[i] + log1p(exp(rho[i])) * eps, eps = eps_in[s][i] when eps_in != NULL else a
- * Philox4x32-10 N(0,1) draw keyed by (seed, stream_id, s*n + i). */
+ * Philox4x32-10 N(0,1) draw keyed by (seed, stream_id, s*n + i).  stream_add (NULL or one uint64 in device memory) is added to
+ * stream_id by the kernel: the per-iteration part of the id stays in HBM, so a captured HIP graph of a training step (the
+ * replacement of torch's generator advancing between iterations, condition_generator_model.py:176-218) draws new numbers on
+ * each replay. */
 int bem_bnn_sample_f32(const float* mu, const float* rho, const float* eps_in, float* out,
-                       int nsets, int64_t n, uint64_t seed, uint64_t stream_id, void* stream);
+                       int nsets, int64_t n, uint64_t seed, uint64_t stream_id, const uint64_t* stream_add, void* stream);
 /* Image preparation of eval.py:146-176: reflect-pad bottom/right of P planes (H,W) -> (Hp,Wp) (numpy 'reflect'), and the
  * x1/s INTER_LINEAR condition image of the padded planes (even s dividing Hp, Wp): mean of the 2x2 centre taps. */
 int bem_pad_reflect_f32(const float* x, float* out, int P, int H, int W, int Hp, int Wp, void* stream);
 int bem_resize_down_f32(const float* x, float* out, int P, int Hp, int Wp, int s, void* stream);
 /* N(0,1) draws from the same Philox4x32-10 stream family as bem_bnn_sample_f32 (torch.randn_like of eval.py:209). */
-int bem_randn_f32(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream);
+int bem_randn_f32(float* out, int64_t n, uint64_t seed, uint64_t stream_id, const uint64_t* stream_add, void* stream);
 /* Stage-I post-processing (eval.py:200-209): c = clamp(pred,0,1); if target_mean: c = clamp(c *
  * target_mean[b_img][ch] / mean_hw(c), 0, 1); c += noise * noise_level.  pred/out (Bn,3,h,w);
  * target_mean (n_img,3) with image index = b / samples_per_image; noise may be NULL. */
@@ -378,19 +394,29 @@ int bem_ss2d_scan_bwd_f32(const float* x0, const float* x1, const float* xd0, co
 
 /* clip_grad_norm_ + torch.optim.AdamW on one flat parameter buffer.  bem_grad_sumsq_f32: acc[0] = sum g^2 (f64, zeroed by the
  * call).  bem_adamw_step_f32: g *= min(1, max_norm / (sqrt(sumsq) + 1e-6)) when max_norm > 0 (read on the device), then the AdamW
- * update with bias corrections of `step` (>= 1); norm_out (or NULL) receives the unclipped total norm. */
+ * update with bias corrections of `step` (>= 1); norm_out (or NULL) receives the unclipped total norm.  hyper (NULL or three floats
+ * in device memory: lr, 1 - beta1^t, sqrt(1 - beta2^t)) overrides lr / step with values read by the kernel -- the per-iteration
+ * inputs of a captured step. */
 int bem_grad_sumsq_f32(const float* g, int64_t n, double* acc, void* stream);
 int bem_adamw_step_f32(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                       float weight_decay, int step, float max_norm, const double* sumsq, float* norm_out, void* stream);
+                       float weight_decay, int step, float max_norm, const double* sumsq, float* norm_out, const float* hyper,
+                       void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Stage-I training: ConditionGenerator.optimize_parameters,
  * basicsr/models/condition_generator_model.py:176-218.  Everything else of that step runs on the Stage-II training entry points.
  * --------------------------------------------------------------------------------------------- */
 
+/* Writes n (<= 512) 32-bit words from HOST memory into device memory at dst, carried as the arguments of one kernel launch on
+ * `stream` (ordered with the launches around it; the host buffer may be reused at once).  The per-iteration inputs of a captured
+ * Stage-I step (stream_add of the samplers, hyper of bem_adamw_step_f32, decay_dev below) are refreshed with it before each replay. */
+int bem_store_words(void* dst, const void* host_words, int n, void* stream);
+
 /* Threshold-EMA prior of a Bayesian leaf (basicsr/bayesian/conv.py:86-98, linear.py:63-74):
- * prior = decay * prior + (1 - decay) * current, for mu and rho; the caller passes decay = min(layer.decay, (1 + step) / (10 + step)). */
-int bem_bnn_prior_ema_f32(float* prior_mu, float* prior_rho, const float* mu, const float* rho, float decay, int64_t n, void* stream);
+ * prior = decay * prior + (1 - decay) * current, for mu and rho; the caller passes decay = min(layer.decay, (1 + step) / (10 + step)),
+ * by value or (decay_dev != NULL) as one float in device memory that the kernel reads -- the form a captured step uses. */
+int bem_bnn_prior_ema_f32(float* prior_mu, float* prior_rho, const float* mu, const float* rho, float decay, const float* decay_dev,
+                          int64_t n, void* stream);
 
 /* out[0] += mean( log sp - log sq + (sq^2 + (mu - prior_mu)^2) / (2 sp^2) - 0.5 ), s = log1p(exp(rho))  (base_layer.py:26-40 kl_div). */
 int bem_bnn_kl_f32(const float* mu, const float* rho, const float* prior_mu, const float* prior_rho, int64_t n, float* out, void* stream);

@@ -624,6 +624,38 @@ def test_selective_scan_cuda_oflex_module(tag):
         ext.fwd(u, delta, A.double(), B, C, D, bias, True, 1, True)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("L", [7, 200, 1000, 4096, 4099])
+def test_selective_scan_cuda_oflex_16bit_inputs(dtype, L):
+    """float16 / bfloat16 u, delta, B, C at the seam (selective_scan_oflex.cpp:166-216): the forward kernel reads the 16-bit tensors itself and
+    must equal, bit for bit, the float32 kernel on the exactly-representable upcast values (every tile shape: 64 / 128 / 256 threads, vector and
+    ragged rows); the backward's casts are the library's own kernels and must equal torch's .to() (round to nearest even, NaN kept)."""
+    import selective_scan_cuda_oflex as ext
+    g = torch.Generator().manual_seed(L)
+    Bn, Dm, N, G = 2, 6, 3, 2
+    u, delta = dev(torch.randn(Bn, Dm, L, generator=g)).to(dtype), dev(torch.randn(Bn, Dm, L, generator=g) * 0.5).to(dtype)
+    A, D, bias = dev(-torch.rand(Dm, N, generator=g) - 0.1), dev(torch.randn(Dm, generator=g)), dev(torch.randn(Dm, generator=g) * 0.1)
+    Bm, Cm = dev(torch.randn(Bn, G, N, L, generator=g)).to(dtype), dev(torch.randn(Bn, G, N, L, generator=g)).to(dtype)
+    o16, _ = ext.fwd(u, delta, A, Bm, Cm, D, bias, True, 1, True)
+    o32, x = ext.fwd(u.float(), delta.float(), A, Bm.float(), Cm.float(), D, bias, True, 1, True)
+    assert o16.dtype == torch.float32 and torch.equal(o16, o32)
+    olow, _ = ext.fwd(u, delta, A, Bm, Cm, D, bias, True, 1, False)
+    assert olow.dtype == dtype and torch.equal(olow, o32.to(dtype))
+    dout = dev(torch.randn(Bn, Dm, L, generator=g))
+    got = ext.bwd(u, delta, A, Bm, Cm, D, bias, dout.to(dtype), x, True, 1)
+    ref = ext.bwd(u.float(), delta.float(), A, Bm.float(), Cm.float(), D, bias, dout.to(dtype).float(), x, True, 1)
+    assert got[0].dtype == dtype and got[1].dtype == dtype and got[3].dtype == torch.float32
+    assert torch.equal(got[0], ref[0].to(dtype)) and torch.equal(got[1], ref[1].to(dtype))
+    for name, a, b in zip(("dA", "dB", "dC", "dD", "dbias"), got[2:], ref[2:]):      # float atomics over the dims of a group / the batch: sum order varies
+        close(a, b.cpu().numpy(), 1e-5, 1e-5, name)
+    # the casts themselves on awkward values
+    v = dev(torch.tensor([0.0, -0.0, 1.0, 65504.0, 7e4, 1e-8, 3.3895314e38, float("inf"), float("nan"), 1.00390625, 1.005859375, 0.1], dtype=torch.float32))
+    low = ext._to16(v, dtype)
+    want = v.to(dtype)
+    assert torch.equal(torch.isnan(low), torch.isnan(want)) and torch.equal(low[~torch.isnan(low)], want[~torch.isnan(want)])
+    assert torch.equal(ext._f32(want[~torch.isnan(want)]), want[~torch.isnan(want)].float())
+
+
 def test_hamilton_product_reference_name():
     from basicsr.QD.quaternion import hamilton_product
     g = load_golden("g3_haar")

@@ -647,6 +647,35 @@ def test_training_driver_save_resume_reproduces_the_run(dev, tmp_path, yml, firs
     assert (st / f"{(total // 3) * 3}.state").is_file()
 
 
+def test_stage1_captured_step_equals_the_launched_one(dev, tmp_path, monkeypatch):
+    """the Stage-I training step replayed from a HIP graph (condition_generator_model.py:176-218 -- zero_grad,
+    forward with the MIM mask, KL + L1, backward, clip, AdamW) against the same 8 iterations launched kernel by kernel
+    (BEM_STAGE1_GRAPH=0).  Everything that changes between iterations is read from device memory in the captured form: the Philox epoch
+    of the weight draws, the learning rate of the warm-up / cosine schedule, Adam's bias corrections, each leaf's EMA decay
+    (1 + step) / (10 + step) -- a stale value of any of them moves the parameters by about one learning rate (2e-4) per iteration.  The
+    scheduler period ends at iteration 4: the mask-less geometry is a second graph and the mask token drops out of the optimizer."""
+    monkeypatch.setenv("BEM_STAGE1_GRAPH", "0")
+    a, ia = _run_driver(tmp_path / "A", "CG_UNet_LOLv1.yml", [], 8)
+    assert not getattr(a, "_graphs", None)
+    monkeypatch.setenv("BEM_STAGE1_GRAPH", "1")
+    b, ib = _run_driver(tmp_path / "B", "CG_UNet_LOLv1.yml", [], 8)
+    captured = [g for g in b._graphs.values() if isinstance(g, dict)]
+    assert len(captured) == 2 and all(isinstance(g["graph"], torch.cuda.CUDAGraph) for g in captured)      # with and without the mask
+    assert a.get_current_learning_rate() == b.get_current_learning_rate()
+    pa, pb = dict(a.net_g.named_parameters()), dict(b.net_g.named_parameters())
+    worst = max(float((pa[k].detach() - pb[k].detach()).abs().max()) for k in pa)
+    assert worst <= 4e-5, worst
+    for (ka, ma), (kb, mb) in zip(a.net_g.named_modules(), b.net_g.named_modules()):
+        if hasattr(ma, "kl_terms"):
+            assert ma.step == mb.step == 8, (ka, ma.step, mb.step)
+            for ta, tb in zip(ma.kl_terms(), mb.kl_terms()):
+                assert float((ta[2] - tb[2]).abs().max()) <= 4e-5 and float((ta[3] - tb[3]).abs().max()) <= 4e-5, ka     # EMA priors
+    sa, sb = a.optimizer_g.state_dict()["state"], b.optimizer_g.state_dict()["state"]
+    assert [float(v["step"]) for v in sa.values()] == [float(v["step"]) for v in sb.values()]
+    assert abs(float(a.log_dict["l_kl"]) - float(b.log_dict["l_kl"])) <= 1e-4 * max(1.0, abs(float(a.log_dict["l_kl"])))
+    assert abs(float(a.log_dict["l_pix"]) - float(b.log_dict["l_pix"])) <= 1e-4
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # BASELINE config 4 at its real size (B 16, 256x256, n_feat 40): the dispatch the bench runs
 # ------------------------------------------------------------------------------------------------------------------
