@@ -200,6 +200,52 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     }
 }
 
+// Planes of a few pixels under many channels (the Stage-I bottleneck: 2x2 .. 4x4 planes, C > 160): the pixel-per-thread form above leaves
+// 4 .. 16 lanes walking C channels one after the other.  Here a workgroup owns ONE pixel and its threads stride over the channels; the
+// three statistics are two workgroup reductions, dgamma / dbeta go to memory as one atomic per (pixel, channel).
+__global__ __launch_bounds__(256) void ln_bwd_chan_kernel(const float* __restrict__ x1, const float* __restrict__ x2, const float* __restrict__ dn,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                          const float* __restrict__ dres, float* __restrict__ dx, float* __restrict__ n_out,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, int C, int64_t L) {
+    __shared__ float sh[3][4];
+    const int64_t b = blockIdx.x / L, p = blockIdx.x % L;
+    const int64_t base = b * C * L + p;
+    const float invC = 1.f / (float)C;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float a0 = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) a0 += x1[base + c * L] + (x2 ? x2[base + c * L] : 0.f);
+    a0 = wave_sum(a0);
+    if (lane == 0) sh[0][wv] = a0;
+    __syncthreads();
+    const float mu = (sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]) * invC;
+    __syncthreads();
+    float var = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float d = x1[base + c * L] + (x2 ? x2[base + c * L] : 0.f) - mu;
+        const float g = dn[base + c * L] * gamma[c];
+        var = fmaf(d, d, var);
+        s1 += g;
+        s2 = fmaf(g, d, s2);
+    }
+    var = wave_sum(var); s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) { sh[0][wv] = var; sh[1][wv] = s1; sh[2][wv] = s2; }
+    __syncthreads();
+    var = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+    s1 = (sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]) * invC;
+    const float rstd = rsqrtf(var * invC + eps);
+    s2 = (sh[2][0] + sh[2][1] + sh[2][2] + sh[2][3]) * invC * rstd;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float xh = (x1[base + c * L] + (x2 ? x2[base + c * L] : 0.f) - mu) * rstd;
+        const float d = dn[base + c * L];
+        float r = rstd * (d * gamma[c] - s1 - xh * s2);
+        if (dres) r += dres[base + c * L];
+        dx[base + c * L] = r;
+        if (n_out) n_out[base + c * L] = fmaf(xh, gamma[c], beta[c]);
+        atomicAdd(dgamma + c, d * xh);
+        atomicAdd(dbeta + c, d);
+    }
+}
+
 // Faster form for C <= 160: the four wavefronts of a workgroup split the channels of the same 64 pixels (CPT = ceil(C / 4) each),
 // x and dn are read ONCE into registers (all loads of a tile issue back to back), the per-pixel statistics are combined through
 // LDS (two barriers per tile), dgamma / dbeta accumulate in registers over the workgroup's tiles (one atomic per channel at the end).
@@ -598,6 +644,10 @@ extern "C" int bem_ln_bwd_f32(const float* x1, const float* x2, const float* dn,
         else BEM_LNB(20, 8);
 #undef BEM_LNB
 #undef BEM_LNB3
+        return bem_check_launch("ln_bwd");
+    }
+    if (L <= 16) {
+        ln_bwd_chan_kernel<<<dim3((unsigned)(B * L)), 256, 0, s>>>(x1, x2, dn, gamma, beta, eps, dres, dx, n_out, dgamma, dbeta, C, L);
         return bem_check_launch("ln_bwd");
     }
     const int64_t tiles = cdiv64(L, 256);

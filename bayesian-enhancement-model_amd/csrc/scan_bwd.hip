@@ -499,7 +499,9 @@ extern "C" int bem_ss2d_scan_bwd_f32(const float* x0, const float* x1, const flo
 #undef BEM_BWD_ROWS
     }
     const int grid = C * B * 2;
-    if (L <= 1024)
+    if (L <= 256)         // Stage-I planes (8x8 .. 2x2 of 128x128 crops): one wavefront per row
+        ss2d_scan_bwd_kernel<64, 4><<<grid, 64, 0, s>>>(x0, x1, xd0, xd1, dy0, dy1, dtw, dtb, A, Ds, dx0, dx1, dxd0, dxd1, dAlog, dDs, ddtw, ddtb, B, C, L, R, xbs0, xbs1);
+    else if (L <= 1024)
         ss2d_scan_bwd_kernel<256, 4><<<grid, 256, 0, s>>>(x0, x1, xd0, xd1, dy0, dy1, dtw, dtb, A, Ds, dx0, dx1, dxd0, dxd1, dAlog, dDs, ddtw, ddtb, B, C, L, R, xbs0, xbs1);
     else
         ss2d_scan_bwd_kernel<1024, 4><<<grid, 1024, 0, s>>>(x0, x1, xd0, xd1, dy0, dy1, dtw, dtb, A, Ds, dx0, dx1, dxd0, dxd1, dAlog, dDs, ddtw, ddtb, B, C, L, R, xbs0, xbs1);

@@ -183,7 +183,9 @@ int launch_wgrad_t(WgK k, hipStream_t s) {
     k.total_chunks = k.B * k.tiles;
     // every pixel split ends in MC x NC float atomics onto the same dW block: few, long splits (about two workgroups per CU)
     const int target = std::max(1, 512 / (ny * nz));
-    k.chunks_per_wg = std::max(8, cdiv(k.total_chunks, target));
+    // ... unless the whole problem is a handful of chunks (Stage I: 8x8 .. 2x2 planes): there one workgroup walking them one after the
+    // other is pure latency, and the few extra atomics cost nothing
+    k.chunks_per_wg = std::max(k.total_chunks >= 256 ? 8 : 2, cdiv(k.total_chunks, target));
     const int nx = cdiv(k.total_chunks, k.chunks_per_wg);
     const size_t shm = (size_t)(MC + NC) * LDR * sizeof(float);
     static_assert((MC + NC) * LDR * sizeof(float) <= 64 * 1024, "dynamic LDS above 64 KiB needs hipFuncSetAttribute");

@@ -84,7 +84,8 @@ def test_pixel_unshuffle_and_sums(dev):
     close(ops.add(x.to(dev), y.to(dev), 0.25), x + 0.25 * y, 1e-7, what="add")
 
 
-@pytest.mark.parametrize("shape", [(2, 40, 16, 12), (1, 7, 9, 5), (2, 160, 8, 8), (1, 80, 33, 20)])
+@pytest.mark.parametrize("shape", [(2, 40, 16, 12), (1, 7, 9, 5), (2, 160, 8, 8), (1, 80, 33, 20),
+                                   (3, 640, 2, 2), (2, 320, 4, 4), (2, 200, 1, 3), (2, 320, 5, 4)])     # C > 160: one workgroup per pixel on planes <= 16 pixels, pixel-per-thread above
 @pytest.mark.parametrize("two", [False, True])
 def test_ln_bwd(dev, shape, two):
     from bem import ops
@@ -226,6 +227,8 @@ def _ss2d_torch(x0, x1, xd0, xd1, dtw, dtb, A, Ds):
 
 
 @pytest.mark.parametrize("B,C,L,R", [(2, 8, 192, 3), (1, 5, 77, 2), (1, 4, 1030, 1), (1, 3, 4100, 3), (1, 2, 9000, 2),
+                                     (3, 7, 64, 5), (2, 6, 16, 10), (2, 3, 4, 10), (1, 4, 256, 3), (1, 4, 300, 3),       # Stage-I planes: one wavefront per row
+
                                      # whole-row channel-blocked forms (full and partial channel groups)
                                      (2, 5, 1024, 2), (1, 6, 1024, 1), (1, 5, 4096, 3), (1, 9, 1024, 5), (1, 3, 256, 10), (1, 5, 16384, 3)])
 def test_ss2d_scan_bwd(dev, B, C, L, R):
