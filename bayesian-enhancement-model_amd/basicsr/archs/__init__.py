@@ -6,7 +6,7 @@ from basicsr.utils.registry import ARCH_REGISTRY
 from bem import archs as _a
 
 for _cls in (_a.Network, _a.DecompDualBranchDDWavelet, _a.DecompSingleBranch, _a.DecompDualBranch2DD, _a.DecompDualBranch2,
-             _a.DecompSingleBranchDD):
+             _a.DecompSingleBranchDD, _a.DecompDualBranch):
     if _cls.__name__ not in ARCH_REGISTRY:
         ARCH_REGISTRY.register(_cls)
 

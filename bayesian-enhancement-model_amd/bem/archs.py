@@ -399,6 +399,137 @@ class DecompDualBranch2(_DualBranchFullRes):
 
 
 # ------------------------------------------------------------------------------------------------
+# Stage-II: DecompDualBranch (basicsr/archs/DecompModel_arch.py:101-366) -- two U-Nets, one cross-fusion, SE + spatial attention
+# ------------------------------------------------------------------------------------------------
+class CrossFusionBlock(nn.Module):
+    """DecompModel_arch.py:57-66: x_tgt + gate * transform(x_src).  The gate is folded into the 1x1 weights and bias (row scaling, cached per
+    weight version), so the block is one limb GEMM with x_tgt as its residual."""
+
+    def __init__(self, ch):
+        super().__init__()
+        self.transform = PwConv2d(ch, ch, bias=True)
+        self.gate = nn.Parameter(torch.ones(1, ch, 1, 1))
+        self._cache = _Cache()
+
+    def forward(self, x_src, x_tgt):
+        _need_cuda(x_src)
+        if grad_mode(self):
+            raise BemNativeError("CrossFusionBlock: inference only (DecompDualBranch has no training kernels)")
+        t, C = self.transform, self.transform.out_channels
+        Wp, b = self._cache.get("gated", [t.weight, t.bias, self.gate], lambda: (
+            ops.pack_pw_weight(ops.row_scale(t.weight.detach().reshape(C, C).contiguous(), self.gate.detach().reshape(C).contiguous())),
+            ops.row_scale(t.bias.detach().contiguous(), self.gate.detach().reshape(C).contiguous())))
+        return ops.pw_gemm(x_src, Wp, C, bias=b, res=x_tgt)
+
+
+class SEBlock(nn.Module):
+    """DecompModel_arch.py:68-83.  ``gate(x)`` returns the (B,C) channel factors; the multiplication happens inside the spatial attention
+    that follows it."""
+
+    def __init__(self, channel, reduction=16):
+        super().__init__()
+        self.fc = nn.Sequential(nn.Linear(channel, channel // reduction, bias=False), nn.ReLU(inplace=True),
+                                nn.Linear(channel // reduction, channel, bias=False), nn.Sigmoid())
+
+    def gate(self, x):
+        _need_cuda(x)
+        return ops.se_gate(x, self.fc[0].weight.detach(), self.fc[2].weight.detach())
+
+    def forward(self, x):
+        raise BemNativeError("SEBlock is applied through SpatialAttention.forward(x, chan_scale=se.gate(x)); it has no standalone forward here")
+
+
+class SpatialAttention(nn.Module):
+    """DecompModel_arch.py:85-99 (kernel 7, or 3)."""
+
+    def __init__(self, kernel_size=7):
+        super().__init__()
+        if kernel_size not in (3, 7):
+            raise ValueError("kernel size must be 3 or 7")
+        self.conv = nn.Conv2d(2, 1, kernel_size, padding=kernel_size // 2, bias=False)
+
+    def forward(self, x, chan_scale=None):
+        _need_cuda(x)
+        if grad_mode(self):
+            raise BemNativeError("SpatialAttention: inference only (DecompDualBranch has no training kernels)")
+        return ops.spatial_attention(x, self.conv.weight.detach(), chan_scale)
+
+
+class DecompDualBranch(nn.Module):
+    """DecompModel_arch.py:101-366: the image's two quaternion maps (4 channels each; the condition half of the 6-channel input is not
+    read, :294) through two U-Nets with their own bottlenecks.  State-dict keys follow the reference: branch 1 without suffix, branch 2
+    with the suffix ``2``.  Inference only."""
+
+    def __init__(self, in_channels=3, out_channels=3, n_feat=40, stage=1, num_blocks=[2, 2, 2], d_state=1, ssm_ratio=1,
+                 mlp_ratio=4, mlp_type="gdmlp", use_pixelshuffle=False, drop_path=0.0, use_illu=False, sam=False,
+                 last_act=None, decomp_model="model1"):
+        super().__init__()
+        self.stage = stage
+        self.num_levels = len(num_blocks)
+        if isinstance(d_state, int):
+            d_state = [d_state] * self.num_levels
+        if decomp_model not in ("model1", "model2", "model3", "model4"):
+            raise ValueError(f"Unknown decomp_model: {decomp_model}")
+        self.decomp = Decomp.from_shipped(decomp_model, wavelet_out=False)
+        for s_ in ("", "2"):
+            fc = Conv2dK(4, n_feat, 3, 1, 1, bias=True)
+            nn.init.kaiming_normal_(fc.weight, mode="fan_out", nonlinearity="linear")
+            nn.init.zeros_(fc.bias)
+            setattr(self, "first_conv" + s_, fc)
+            enc, cur = nn.ModuleList(), n_feat
+            for i in range(self.num_levels - 1):
+                enc.append(make_vss_level(cur, num_blocks[i], d_state[i], ssm_ratio, mlp_ratio, mlp_type))
+                cur *= 2
+            setattr(self, "encoders" + s_, enc)
+            setattr(self, "bottleneck" + s_, make_vss_level(cur, num_blocks[-1], d_state[-1], ssm_ratio, mlp_ratio, mlp_type))
+            d, decs = cur, nn.ModuleList()
+            for i in range(self.num_levels - 2, -1, -1):
+                decs.append(_decoder(d, num_blocks[i], d_state[i], ssm_ratio, mlp_ratio, mlp_type))
+                d //= 2
+            setattr(self, "decoders" + s_, decs)
+            pj = Conv2dK(n_feat, 4, 3, 1, 1, bias=True)
+            nn.init.zeros_(pj.bias)
+            setattr(self, "proj" + s_, pj)
+            setattr(self, "down_layers" + s_, nn.ModuleList([conv_down(n_feat * (2 ** i)) for i in range(self.num_levels - 1)]))
+        self.last_act = _check_last_act(last_act)
+        self.cross_fusion_12, self.cross_fusion_21 = CrossFusionBlock(cur), CrossFusionBlock(cur)
+        self.bottleneck_se, self.bottleneck_se2 = SEBlock(cur), SEBlock(cur)
+        self.spatial_attention, self.spatial_attention2 = SpatialAttention(), SpatialAttention()
+        self.apply(_init_weights)
+
+    def forward(self, x, mask=None):
+        _need_cuda(x)
+        if grad_mode(self):
+            raise BemNativeError("DecompDualBranch: inference only (call eval() or run under torch.no_grad())")
+        with torch.no_grad():
+            x = x.contiguous()
+            B, _, H, W = x.shape
+            qi = self.decomp(x, 0)                                      # (B,8,H,W) = [Q1 | Q2] of the image channels
+            feats, skips = [], []
+            for bi, s_ in enumerate(("", "2")):
+                f = getattr(self, "first_conv" + s_)(qi, cin_slice=(4 * bi, 4))
+                sk = []
+                for i in range(self.num_levels - 1):
+                    f = getattr(self, "encoders" + s_)[i](f)
+                    sk.append(f)
+                    f = getattr(self, "down_layers" + s_)[i](f)
+                feats.append(f); skips.append(sk)
+            f2 = self.cross_fusion_12(feats[0], feats[1])               # branch 2 takes from branch 1 first ...
+            f1 = self.cross_fusion_21(f2, feats[0])                     # ... and branch 1 from the fused branch 2 (:311-312)
+            out8 = torch.empty(B, 8, H, W, device=x.device, dtype=x.dtype)
+            for bi, (s_, f) in enumerate((("", f1), ("2", f2))):
+                f = getattr(self, "bottleneck" + s_)(f)
+                f = getattr(self, "spatial_attention" + s_)(f, chan_scale=getattr(self, "bottleneck_se" + s_).gate(f))
+                for j, dec in enumerate(getattr(self, "decoders" + s_)):
+                    f = dec["up"](f)
+                    f = dec["fuse"](f, x2=skips[bi][self.num_levels - 2 - j], in_mode=2)
+                    f = dec["block"](f)
+                ops.copy_channels(getattr(self, "proj" + s_)(f), out8, 4 * bi)
+            out = ops.hamilton(out8)
+        return [x, out]
+
+
+# ------------------------------------------------------------------------------------------------
 # Stage-II: DecompSingleBranch (BASELINE config 1)
 # ------------------------------------------------------------------------------------------------
 class DecompSingleBranch(nn.Module):

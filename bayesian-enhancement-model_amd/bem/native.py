@@ -67,6 +67,9 @@ SIGNATURES = {
     "bem_pw_x6_packed_elems": [I, I],
     "bem_bnn_sample_pack_x6": [P, P, P, P, I, I, I, U64, U64, P, I, P],
     "bem_store_words": [P, P, I, P],
+    "bem_row_scale_f32": [P, P, P, I, I, P],
+    "bem_se_gate_f32": [P, P, P, P, I, I, I, P],
+    "bem_spatial_attention_f32": [P, P, P, P, P, I, I, I, I, I, P],
     "bem_bnn_prior_ema_f32": [P, P, P, P, F, P, I64, P],
     "bem_bnn_kl_f32": [P, P, P, P, I64, P, P],
     "bem_bnn_kl_bwd_f32": [P, P, P, P, I64, P, P, P, P],

@@ -787,6 +787,44 @@ def plane_mean(x, h=None, w=None):
     return out
 
 
+# --------------------------------------------------------------------------- DecompDualBranch's bottleneck blocks ----
+def row_scale(w, scale):
+    """w (M, ...) * scale (M) along the first axis."""
+    _chk(w, "w"); _chk(scale, "scale")
+    M = w.shape[0]
+    if scale.numel() != M:
+        raise ValueError("row_scale: one factor per row")
+    out = torch.empty_like(w)
+    check(lib().bem_row_scale_f32(_p(w), _p(scale), _p(out), M, w.numel() // M, _stream()), "row_scale")
+    return out
+
+
+def se_gate(x, w1, w2):
+    """SEBlock's per-channel gate (B,C) = sigmoid(w2 relu(w1 mean_hw(x)))."""
+    _chk(x, "x"); _chk(w1, "w1"); _chk(w2, "w2")
+    B, C = x.shape[0], x.shape[1]
+    Cr = w1.shape[0]
+    if tuple(w1.shape) != (Cr, C) or tuple(w2.shape) != (C, Cr):
+        raise ValueError("se_gate: weight shapes")
+    mean = plane_mean(x)
+    y = torch.empty(B, C, device=x.device, dtype=x.dtype)
+    check(lib().bem_se_gate_f32(_p(mean), _p(w1), _p(w2), _p(y), B, C, Cr, _stream()), "se_gate")
+    return y
+
+
+def spatial_attention(x, w, chan_scale=None):
+    """x * chan_scale * sigmoid(conv_kxk([mean_c, max_c](x * chan_scale))); w (1,2,k,k)."""
+    _chk(x, "x"); _chk(w, "w"); _chk(chan_scale, "chan_scale", optional=True)
+    B, C, H, W = x.shape
+    k = w.shape[-1]
+    if tuple(w.shape) != (1, 2, k, k) or (chan_scale is not None and tuple(chan_scale.shape) != (B, C)):
+        raise ValueError("spatial_attention: weight / gate shapes")
+    ws = torch.empty(B, 2, H, W, device=x.device, dtype=x.dtype)
+    out = torch.empty_like(x)
+    check(lib().bem_spatial_attention_f32(_p(x), _p(chan_scale), _p(w), _p(ws), _p(out), B, C, H, W, k, _stream()), "spatial_attention")
+    return out
+
+
 def cond_postproc(pred, target_mean, noise, samples_per_image, noise_level):
     _chk(pred, "pred"); _chk(target_mean, "target_mean", optional=True); _chk(noise, "noise", optional=True)
     Bn, C, h, w = pred.shape

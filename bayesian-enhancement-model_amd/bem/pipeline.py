@@ -60,9 +60,17 @@ class BEMPipeline:
             noise = ops.randn(tuple(pred.shape), pred.device, seed, (1 << 62) | (rank << 44) | SampleCtx._epoch)
         conds = ops.cond_postproc(pred, tmean, noise if self.noise_level else None, N, self.noise_level)
         cond_up = ops.bilinear_up(conds, self.scale)                             # (B*N,3,Hp,Wp)
-        d_img = self.net2.decompose(pad, 0)                                      # once per image
-        d_cond = self.net2.decompose(cond_up, 0)
-        raw = self.net2.forward_decomposed(d_img, d_cond, None if N == 1 else N)
+        if hasattr(self.net2, "forward_decomposed"):
+            d_img = self.net2.decompose(pad, 0)                                  # once per image
+            d_cond = self.net2.decompose(cond_up, 0)
+            raw = self.net2.forward_decomposed(d_img, d_cond, None if N == 1 else N)
+        else:
+            # Stage-II archs without a separable decomposition stage (DecompDualBranch, the *2 / *DD / SingleBranch siblings): the
+            # reference's own call per candidate, net(cat(img, cond)) (eval.py:211-213), as one batch of B*N rows
+            x2 = torch.empty(B * N, 6, Hp, Wp, device=pad.device, dtype=pad.dtype)
+            ops.copy_channels(pad[:, None].expand(B, N, 3, Hp, Wp).reshape(B * N, 3, Hp, Wp).contiguous(), x2, 0)
+            ops.copy_channels(cond_up, x2, 3)
+            raw = self.net2(x2)[-1]
         final, psnr = ops.candidate_finalize(raw, None if targets is None else targets.contiguous(), N, h, w,
                                              bool(gt_mean and targets is not None))
         return dict(conds=conds, raw=raw, final=final, psnr=psnr, N=N)

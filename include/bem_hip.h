@@ -243,6 +243,20 @@ int bem_space_to_depth_f32(const float* x, float* out, int B, int C, int H, int 
 int bem_pixel_shuffle2_f32(const float* x, float* out, int B, int C, int H, int W, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * DecompDualBranch's bottleneck blocks (basicsr/archs/DecompModel_arch.py:57-99).
+ * ------------------------------------------------------------------------------------------- */
+/* out[m][k] = w[m][k] * scale[m]: folds CrossFusionBlock's per-channel gate (:57-66, x_tgt + gate * (W x_src + b)) into W (M,K) and,
+ * with K = 1, into b; the block then runs as bem_pw_gemm_x6_f32 with x_tgt as the residual. */
+int bem_row_scale_f32(const float* w, const float* scale, float* out, int M, int K, void* stream);
+/* SEBlock's gate (:68-83): y (B,C) = sigmoid(w2 relu(w1 mean)), mean (B,C) from bem_plane_mean_f32, w1 (Cr,C), w2 (C,Cr), no biases. */
+int bem_se_gate_f32(const float* mean, const float* w1, const float* w2, float* y, int B, int C, int Cr, void* stream);
+/* SpatialAttention (:85-99) of x * chan_scale (chan_scale (B,C) = the SE gate that precedes it, :318-324, or NULL):
+ * out = x * chan_scale * sigmoid(conv_kxk([mean_c, max_c](x * chan_scale))), w (1,2,k,k), k = 3 or 7, zero padding k/2, no bias;
+ * map_ws: (B,2,H,W) floats of workspace; x, out (B,C,H,W). */
+int bem_spatial_attention_f32(const float* x, const float* chan_scale, const float* w, float* map_ws, float* out, int B, int C, int H, int W,
+                              int k, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Bayesian sampling + Monte-Carlo loop pieces (basicsr/bayesian/conv.py:106-114, eval.py:199-264).
  * ------------------------------------------------------------------------------------------- */
 /* out[s][i] = mu[i] + log1p(exp(rho[i])) * eps, eps = eps_in[s][i] when eps_in != NULL else a

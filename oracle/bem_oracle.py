@@ -422,6 +422,54 @@ def dualbranch2_ref(sd: SD, x, scan=selective_scan_ref, pre: str = ""):
     return hamilton_ref(o1, o2)[:, 1:]
 
 
+def se_block_ref(sd: SD, pre: str, x):
+    """SEBlock (DecompModel_arch.py:68-83): x * sigmoid(W2 relu(W1 mean_hw(x)))."""
+    y = torch.relu(x.mean((2, 3)) @ sd[pre + "fc.0.weight"].t()) @ sd[pre + "fc.2.weight"].t()
+    return x * torch.sigmoid(y)[:, :, None, None]
+
+
+def spatial_attention_ref(sd: SD, pre: str, x):
+    """SpatialAttention (DecompModel_arch.py:85-99): x * sigmoid(conv7x7([mean_c x, max_c x]))."""
+    w = sd[pre + "conv.weight"]
+    a = F.conv2d(torch.cat([x.mean(1, keepdim=True), x.max(1, keepdim=True)[0]], 1), w, padding=w.shape[-1] // 2)
+    return x * torch.sigmoid(a)
+
+
+def cross_fusion_ref(sd: SD, pre: str, x_src, x_tgt):
+    """CrossFusionBlock (DecompModel_arch.py:57-66): x_tgt + gate * (W x_src + b)."""
+    return x_tgt + sd[pre + "gate"] * F.conv2d(x_src, sd[pre + "transform.weight"], sd[pre + "transform.bias"])
+
+
+def dualbranch_ref(sd: SD, x, scan=selective_scan_ref, pre: str = ""):
+    """DecompDualBranch.forward (DecompModel_arch.py:292-352): the image's two quaternion maps (the condition channels are not read) through
+    two U-Nets that meet once, by cross-fusion at the deepest encoder level (branch 2 first, branch 1 from the fused branch 2); SE + spatial
+    attention after each bottleneck; Hamilton product of the two 4-channel outputs, imaginary parts."""
+    q = decomp_full_ref(sd, pre + "decomp.", x[:, 0:3])
+    nl = _levels(sd, pre + "down_layers.") + 1
+    feats, skips = [], []
+    for s_, qb in zip(("", "2"), q):
+        f = F.conv2d(qb, sd[f"{pre}first_conv{s_}.weight"], sd[f"{pre}first_conv{s_}.bias"], padding=1)
+        sk = []
+        for i in range(nl - 1):
+            f = _blocks(sd, f"{pre}encoders{s_}.{i}.", f, None, scan)
+            sk.append(f)
+            f = F.conv2d(f, sd[f"{pre}down_layers{s_}.{i}.weight"], None, stride=2, padding=1)
+        feats.append(f); skips.append(sk)
+    f2 = cross_fusion_ref(sd, pre + "cross_fusion_12.", feats[0], feats[1])
+    f1 = cross_fusion_ref(sd, pre + "cross_fusion_21.", f2, feats[0])
+    outs = []
+    for s_, f, sk in (("", f1, skips[0]), ("2", f2, skips[1])):
+        f = _blocks(sd, f"{pre}bottleneck{s_}.", f, None, scan)
+        f = spatial_attention_ref(sd, f"{pre}spatial_attention{s_}.", se_block_ref(sd, f"{pre}bottleneck_se{s_}.", f))
+        for j in range(nl - 1):
+            d = f"{pre}decoders{s_}.{j}."
+            f = F.conv_transpose2d(f, sd[d + "up.weight"], sd[d + "up.bias"], stride=2)
+            f = F.conv2d(torch.cat([f, sk[nl - 2 - j]], 1), sd[d + "fuse.weight"])
+            f = _blocks(sd, d + "block.", f, None, scan)
+        outs.append(F.conv2d(f, sd[f"{pre}proj{s_}.weight"], sd[f"{pre}proj{s_}.bias"], padding=1))
+    return hamilton_ref(outs[0], outs[1])[:, 1:]
+
+
 def singlebranchdd_ref(sd: SD, x, scan=selective_scan_ref, pre: str = ""):
     """DecompSingleBranchDD.forward (DecompSingleBranchDD_arch.py:205-250)."""
     q1i, q2i = decomp_full_ref(sd, pre + "decomp.", x[:, 0:3])

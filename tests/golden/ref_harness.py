@@ -108,6 +108,7 @@ def load():
         ns.dd = importlib.import_module("basicsr.archs.DecompDualBranchDD_arch")
         ns.dual2 = importlib.import_module("basicsr.archs.DecompDualBranch_arch")
         ns.singledd = importlib.import_module("basicsr.archs.DecompSingleBranchDD_arch")
+        ns.dualse = importlib.import_module("basicsr.archs.DecompModel_arch")
     ns.torch = torch
     _loaded["ns"] = ns
     return ns

@@ -89,6 +89,22 @@ def test_parse_and_build_model_key_contract(yml, arch, mtype):
     assert sorted(mine) == sorted(ref)
 
 
+def test_dualbranch_se_attention_key_contract():
+    """Options/DecompDualBranch_4.yml -> ARCH_REGISTRY 'DecompDualBranch' (basicsr/archs/DecompModel_arch.py:101): state-dict keys and
+    shapes of the full-width net equal the reference's (recorded in g12_dualbranch.npz), so its checkpoints load strictly."""
+    from basicsr.models import build_model
+    from basicsr.utils.options import parse
+    opt = parse(os.path.join(PKG, "Options", "DecompDualBranch_4.yml"), is_train=False)
+    opt["num_gpu"] = 0
+    net = build_model(opt).net_g
+    assert type(net).__name__ == "DecompDualBranch"
+    ref = np.load(os.path.join(GOLDEN, "g12_dualbranch.npz"))["contract"].tolist()
+    mine = [f"{k}|{','.join(map(str, v.shape))}" for k, v in net.state_dict().items()]
+    assert sorted(mine) == sorted(ref)
+    import basicsr.archs.DecompModel_arch as shim
+    assert shim.DecompDualBranch is type(net) and shim.SEBlock and shim.SpatialAttention and shim.CrossFusionBlock
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/Options"), reason="reference tree not present")
 def test_reference_option_files_parse():
     """Every shipped option file of the supported archs parses and builds through the mirror."""

@@ -221,6 +221,69 @@ def test_sibling_archs_golden(tag, cls, dm):
     close(res[0], g["first"], 0, 0, cls + " passthrough")
 
 
+def test_dualbranch_se_attention_golden():
+    """DecompDualBranch (DecompModel_arch.py:101-366) against the reference's own run (g12): the three blocks it adds on the tensors the
+    reference's modules saw (forward hooks: cross-fusion as a gated GEMM with residual, SE gate + 7x7 spatial attention in one pass),
+    then the whole net."""
+    import bem.archs as A
+    from bem import ops
+    g = load_golden("g12_dualbranch")
+    net = A.DecompDualBranch(in_channels=6, out_channels=3, n_feat=16, d_state=[1, 1, 1], ssm_ratio=1, mlp_ratio=4, mlp_type="gdmlp",
+                             use_pixelshuffle=True, drop_path=0.0, sam=False, stage=1, num_blocks=[1, 1, 1], decomp_model="model4")
+    assert set(net.state_dict().keys()) == set(g["keys"].tolist())
+    sd = dict(g["sd"]); sd.update({k: v for k, v in qd_state_dict("model4").items() if k in net.state_dict()})
+    net.load_state_dict(sd, strict=True)
+    net.cuda().eval()
+    t = {k: torch.as_tensor(v).cuda() for k, v in g["taps"].items()}
+    for s_ in ("", "2"):
+        se, sa = getattr(net, "bottleneck_se" + s_), getattr(net, "spatial_attention" + s_)
+        x = t[f"bottleneck_se{s_}.in0"]
+        y = se.gate(x)
+        close(x * y[:, :, None, None], t[f"bottleneck_se{s_}.out"], 1e-5, 1e-6, "SE" + s_)
+        close(sa(x, chan_scale=y), t[f"spatial_attention{s_}.out"], 1e-5, 1e-6, "SE + attention" + s_)
+        close(sa(t[f"spatial_attention{s_}.in0"]), t[f"spatial_attention{s_}.out"], 1e-5, 1e-6, "attention alone" + s_)
+    for name in ("cross_fusion_12", "cross_fusion_21"):
+        close(getattr(net, name)(t[name + ".in0"], t[name + ".in1"]), t[name + ".out"], 1e-5, 2e-6, name)
+    # 3x3 attention kernel (the class accepts 3 or 7) against torch on a ragged plane
+    gen = torch.Generator().manual_seed(5)
+    x3, w3 = torch.randn(2, 5, 7, 9, generator=gen).cuda(), torch.randn(1, 2, 3, 3, generator=gen).cuda()
+    m3 = torch.cat([x3.mean(1, keepdim=True), x3.max(1, keepdim=True)[0]], 1)
+    close(ops.spatial_attention(x3, w3), x3 * torch.sigmoid(torch.nn.functional.conv2d(m3.cpu(), w3.cpu(), padding=1)).cuda(), 1e-5, 1e-6, "3x3")
+    res = net(g["x"].cuda())
+    close(res[-1], g["out"], 2e-3, 1e-4, "DecompDualBranch")
+    close(res[0], g["first"], 0, 0, "passthrough")
+    net.train()
+    with pytest.raises(Exception):
+        net(g["x"].cuda())
+
+
+def test_mc_pipeline_with_dualbranch_stage2_vs_oracle():
+    """The Monte-Carlo loop of eval.py:199-297 with DecompDualBranch (Options/DecompDualBranch_4.yml) as the Stage-II net -- an arch whose
+    decomposition cannot be hoisted out of the sample loop: N = 3 candidates of one 48x40 image (padded to 64x64) with injected weight
+    epsilons and condition noise against oracle.eval_mc_ref(stage2=dualbranch_ref); PSNR within the north star's 1e-3 dB, same selection."""
+    import bem.archs as A
+    from bem.pipeline import BEMPipeline, build_nets, synthetic_pair
+    net1, _ = build_nets(n_feat=16, num_blocks=(1, 1, 1), device="cuda")
+    torch.manual_seed(5)
+    net2 = A.DecompDualBranch(in_channels=6, n_feat=16, d_state=[1, 1, 1], mlp_type="gdmlp", num_blocks=[1, 1, 1], decomp_model="model4").cuda().eval()
+    sd1 = {k: v.detach().cpu() for k, v in net1.state_dict().items()}
+    sd2 = {k: v.detach().cpu() for k, v in net2.state_dict().items()}
+    lq, gt = synthetic_pair((1, 3, 48, 40), seed=12)
+    N = 3
+    g = torch.Generator().manual_seed(22)
+    eps_cpu = [{(k[:-len("mu_weight")] + "weight" if k.endswith("mu_weight") else k[:-len("mu_bias")] + "bias"): torch.randn(v.shape, generator=g)
+                for k, v in sd1.items() if k.endswith(("mu_weight", "mu_bias"))} for _ in range(N)]
+    noise = [torch.randn(1, 3, 4, 4, generator=g) for _ in range(N)]
+    ref = O.eval_mc_ref(sd1, sd2, lq, gt, N, eps_list=eps_cpu, noise_list=noise, gt_mean=True, scan=O.selective_scan_c, stage2=O.dualbranch_ref)
+    pipe = BEMPipeline(net1, net2, 16, 0.1)
+    eps = {k: torch.stack([e[k] for e in eps_cpu]).cuda() for k in eps_cpu[0]}
+    out = pipe.enhance(lq.cuda(), gt.cuda(), N, gt_mean=True, eps=eps, noise=torch.cat(noise).cuda())
+    for i in range(N):
+        assert abs(float(out["psnr"][i]) - ref["psnr"][i]) < 1e-3, (i, float(out["psnr"][i]), ref["psnr"][i])
+        close(out["final"][i].permute(1, 2, 0), ref["finals"][i], 0, 5e-4, f"candidate {i}")
+    assert int(out["best"][0]) == ref["best"]
+
+
 # ----------------------------------------------------------------------------- float64 yardstick --
 def _scan64(u, delta, A, B, C, D=None, delta_bias=None, delta_softplus=True):
     """selective_scan_ref's recurrence with nothing cast down (test-only: the reference casts to f32)."""

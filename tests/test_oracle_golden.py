@@ -110,6 +110,23 @@ def test_g9_sibling_archs(tag, fn, dm):
     close(fn(sd, g["x"], O.selective_scan_c), g["out"], rtol=1e-3, atol=2e-5)
 
 
+def test_g12_dualbranch_se_attention():
+    """DecompDualBranch (DecompModel_arch.py:101-366: cross-fusion, SE block, spatial attention) against the reference's own output."""
+    g = load_golden("g12_dualbranch")
+    sd = dict(g["sd"])
+    sd.update(qd_state_dict("model4"))
+    close(O.dualbranch_ref(sd, g["x"], O.selective_scan_c), g["out"], rtol=1e-3, atol=2e-5)
+    # the blocks themselves, on the tensors the reference's modules saw (forward hooks): the U-Net's LayerNorms hide most of a gate from the output
+    t = g["taps"]
+    for name, fn in (("bottleneck_se", O.se_block_ref), ("bottleneck_se2", O.se_block_ref), ("spatial_attention", O.spatial_attention_ref),
+                     ("spatial_attention2", O.spatial_attention_ref)):
+        want = torch.as_tensor(t[name + ".out"])
+        close(fn(sd, name + ".", torch.as_tensor(t[name + ".in0"])), want, rtol=1e-5, atol=1e-6)
+        assert float((want - torch.as_tensor(t[name + ".in0"])).abs().max()) > 0.05 * float(want.abs().max())      # the gate is not the identity
+    for name in ("cross_fusion_12", "cross_fusion_21"):
+        close(O.cross_fusion_ref(sd, name + ".", torch.as_tensor(t[name + ".in0"]), torch.as_tensor(t[name + ".in1"])), t[name + ".out"], rtol=1e-5, atol=1e-6)
+
+
 def test_g5_decomp_model2_model3():
     """QD model2 (dilated branch convs) and model3 (mini U-Net; eval mode) with the shipped weights: wavelet-domain and full maps
     recorded from the reference (tests/golden/make_golden_r2.py)."""
