@@ -107,10 +107,12 @@ def test_dualbranch_se_attention_key_contract():
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/Options"), reason="reference tree not present")
 def test_reference_option_files_parse():
-    """Every shipped option file of the supported archs parses and builds through the mirror."""
+    """All 14 Decomp* option files the reference ships parse and build through the mirror, unmodified."""
     from basicsr.archs import build_network
     from basicsr.utils.options import parse
-    for f in ("DecompDualBranch2DDWavelet_4.yml", "DecompDualBranch2DDWavelet_1.yml", "DecompSingleBranch_1.yml", "DecompSingleBranch_4.yml"):
+    files = sorted(f for f in os.listdir("/root/reference/Options") if f.startswith("Decomp") and f.endswith(".yml"))
+    assert len(files) == 14, files
+    for f in files:
         opt = parse(os.path.join("/root/reference/Options", f), is_train=False)
         net = build_network(opt["network_g"])
         assert type(net).__name__ == opt["network_g"]["type"]
