@@ -5,10 +5,13 @@ Differences from the reference driver that do not change results:
     its own Bayesian weight sample (per-batch-element weights in the GEMM / depthwise kernels), which is
     what the reference's B=1 loop draws (eval.py:199-211);
   * Stage-I outputs never leave the GPU (the reference copies every sample D2H and back, eval.py:211,219);
-  * decomp(image) is evaluated once per image and shared by its N samples (it does not depend on the sample).
+  * decomp(image) is evaluated once per image and shared by its N samples (it does not depend on the sample) -- and, depending on nothing
+    Stage I produces, on a second HIP stream beside it: Stage I is ~160 kernels on H/16 x W/16 planes that occupy a few CUs each, the
+    decomposition's full-resolution kernels fill the rest of the chip meanwhile (BEM_DECOMP_OVERLAP=0: one stream).
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -23,6 +26,7 @@ class BEMPipeline:
     def __init__(self, net1, net2, scale_down: int = 16, noise_level: float = 0.1):
         self.net1, self.net2 = net1, net2
         self.scale, self.noise_level = scale_down, noise_level
+        self._side = None          # second stream for decomp(image), created on first use
 
     @torch.no_grad()
     def candidates(self, imgs, targets, num_samples: int, gt_mean: bool, deterministic: bool = False,
@@ -51,6 +55,15 @@ class BEMPipeline:
             img_down = ops.resize_down(pad, self.scale)
         hd, wd = img_down.shape[-2:]
         x1 = img_down[:, None].expand(B, N, 3, hd, wd).reshape(B * N, 3, hd, wd)  # (B*N,3,hd,wd): row = image*N + sample
+        hoist = hasattr(self.net2, "forward_decomposed")
+        d_img, main = None, torch.cuda.current_stream()
+        if hoist and os.environ.get("BEM_DECOMP_OVERLAP", "1") != "0":
+            if self._side is None or self._side.device != pad.device:
+                self._side = torch.cuda.Stream(device=pad.device)
+            self._side.wait_stream(main)                                         # pad is ready
+            with torch.cuda.stream(self._side):
+                d_img = self.net2.decompose(pad, 0)                              # once per image, beside Stage I
+            pad.record_stream(self._side)
         set_prediction_type(self.net1, deterministic)
         with sampling(None if deterministic else SampleCtx(B * N, eps, seed, rank=rank)) as ctx:
             pred = self.net1(x1)[-1]
@@ -60,8 +73,12 @@ class BEMPipeline:
             noise = ops.randn(tuple(pred.shape), pred.device, seed, (1 << 62) | (rank << 44) | SampleCtx._epoch)
         conds = ops.cond_postproc(pred, tmean, noise if self.noise_level else None, N, self.noise_level)
         cond_up = ops.bilinear_up(conds, self.scale)                             # (B*N,3,Hp,Wp)
-        if hasattr(self.net2, "forward_decomposed"):
-            d_img = self.net2.decompose(pad, 0)                                  # once per image
+        if hoist:
+            if d_img is None:
+                d_img = self.net2.decompose(pad, 0)                              # once per image
+            else:
+                main.wait_stream(self._side)
+                d_img.record_stream(main)                                        # allocated on the side stream, consumed (and freed) on this one
             d_cond = self.net2.decompose(cond_up, 0)
             raw = self.net2.forward_decomposed(d_img, d_cond, None if N == 1 else N)
         else:
