@@ -786,6 +786,15 @@ class Network(nn.Module):
         try:
             with sampling(ctx):
                 set_module_paths(self)
+                if os.environ.get("BEM_BAYES_BANK", "1") != "0":
+                    from .modules import BayesBank
+                    from .train import STEP_STATE
+                    bank = self.__dict__.get("_bayes_bank")
+                    if bank is None:
+                        bank = self.__dict__["_bayes_bank"] = BayesBank(self)
+                    if bank.ready() and bank.usable(ctx):
+                        bank.sample(ctx, step, STEP_STATE[0])      # every leaf's prior EMA + draw + sample in one launch
+                step.counter0 = ctx.counter if step.bank is None else 0
                 fea = self.first_conv(x.contiguous())
                 if mask is not None:
                     fea = ag.MaskTokenFn.apply(fea, mask, self.mask_token)
@@ -793,6 +802,9 @@ class Network(nn.Module):
                 dec = self.subnets[0](fa)
                 out = self.proj(ag.AddFn.apply(fb, dec))
                 out = ag.BayesAnchorFn.apply(out, step)
+                bank = self.__dict__.get("_bayes_bank")
+                if bank is not None and not bank.ready() and ctx.eps is None:
+                    bank.try_build()                               # this forward went leaf by leaf and recorded its draw order
         finally:
             _TRAIN_STEP[0] = prev
         return [x, out]

@@ -62,7 +62,7 @@ def grad_of(p: torch.Tensor) -> torch.Tensor:
 
 def _pack(holder, key, srcs, make):
     """pack_pw_weight of ``make()`` (an (M,K) matrix), cached on ``holder``."""
-    return _derived(holder).get(key, srcs, lambda: ops.pack_pw_weight(make().contiguous()))
+    return _derived(holder).get(key, srcs, lambda: ops.pack_pw_weight(make() if ops.USE_X6 else make().contiguous()))
 
 
 def _w2d(w):
@@ -477,11 +477,17 @@ class BayesStep:
     def __init__(self):
         self.leaves = []
         self.done = False
+        self.bank = None                 # modules.BayesBank when the samples of this forward were drawn by its one launch
 
     def finish(self):
         if self.done:
             return
         self.done = True
+        if self.bank is not None:        # dmu += dw, drho += dw eps sigmoid(rho) for every tensor of the net in one launch
+            ops.bnn_bank_reparam_bwd_(self.bank)
+            for m in self.leaves:
+                m._ws = m._bs = m._eps_w = m._eps_b = m._sample_owner = None
+            return
         for m in self.leaves:
             m.fold_sample_grads()
 
@@ -506,6 +512,13 @@ class KLFn(Function):
     @staticmethod
     def forward(ctx, leaves, *params):
         out = torch.zeros(1, device=params[0].device, dtype=torch.float32)
+        st = getattr(leaves[0], "_sample_owner", None)
+        bank = getattr(st, "bank", None)
+        if bank is not None and len(bank.leaves) == len(leaves) and all(a is b and a._sample_owner is st for a, b in zip(bank.leaves, leaves)):
+            ops.bnn_bank_kl_(bank, out)              # the forward that has just run drew its samples through the bank: same tensors, one launch
+            ctx.bank = bank
+            return out.reshape(())
+        ctx.bank = None
         for m in leaves:
             for mu, rho, pmu, prho in m.kl_terms():
                 ops.bnn_kl_(mu.detach(), rho.detach(), pmu, prho, out)
@@ -515,6 +528,9 @@ class KLFn(Function):
     @staticmethod
     def backward(ctx, g):
         g = g.reshape(1).contiguous().float()
+        if ctx.bank is not None:
+            ops.bnn_bank_kl_bwd_(ctx.bank, g)
+            return (None,) * len(ctx.needs_input_grad)
         for m in ctx.leaves:
             for mu, rho, pmu, prho in m.kl_terms():
                 ops.bnn_kl_bwd_(mu.detach(), rho.detach(), pmu, prho, g, grad_of(mu), grad_of(rho))

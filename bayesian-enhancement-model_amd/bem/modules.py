@@ -263,6 +263,7 @@ class _BayesBase(nn.Module):
                 e = ctx.eps[f"{self.module_path}.{kind}"].reshape((1,) + tuple(mu.shape)).contiguous()
             else:
                 e = ops.randn((1,) + tuple(mu.shape), mu.device, ctx.seed, ctx.next_stream(), ctx.epoch_dev)
+                self.__dict__.setdefault("_draw_order", {})[kind] = ctx.counter - getattr(step, "counter0", 0)   # for BayesBank: same streams
             w = ops.bnn_sample(mu.detach(), rho.detach(), 1, e)[0]
             if kind == "weight":
                 self._ws, self._eps_w = w, e
@@ -321,6 +322,104 @@ class _BayesBase(nn.Module):
         if self.bias:
             b = ops.bnn_sample(self.mu_bias.detach(), self.rho_bias.detach(), ns, eb, ctx.seed, ctx.next_stream(), ctx.epoch_dev)
         return w, b, ns
+
+
+class BayesBank:
+    """All Bayesian tensors of a net as segments of flat arenas, so that the per-tensor steps of a training iteration -- prior EMA + eps
+    draw + weight sample, KL, KL backward, reparameterisation backward (conv.py:84-112, tools.py:76-84) -- are ONE launch each over the
+    whole net (bem_bnn_bank_*) instead of one per tensor (60 leaves / 90 tensors in the shipped Stage-I net: ~630 launches per step).
+
+    The prior buffers of the leaves become views of the bank's prior arenas; the sampled weights, their eps and their gradient buffers
+    are persistent views of the w / eps / gw arenas (the sampling launch zeroes gw).  Parameters and their .grad buffers are addressed by
+    pointer (they usually live in BemAdamW's flat buffers); the tables are rebuilt when any of those pointers changes.  Used for
+    Philox draws only -- injected eps (parity runs) take the per-leaf path."""
+
+    def __init__(self, net):
+        self.leaves = [m for m in net.modules() if isinstance(m, _BayesBase)]
+        self.sig = None
+
+    def ready(self):
+        return self.sig is not None
+
+    def try_build(self):
+        """After a per-leaf Philox forward: every tensor has recorded which stream of the forward it drew from (1 .. S in execution
+        order); the bank gives each segment that same stream, so its draws are the per-leaf path's draws."""
+        order = sorted(m.__dict__.get("_draw_order", {}).get(kind, -1) for m, kind, _, _ in self._tensors())
+        if order == list(range(1, len(order) + 1)) and not torch.cuda.is_current_stream_capturing():
+            self._build()
+
+    def _tensors(self):
+        for m in self.leaves:
+            for kind in ("weight", "bias") if m.bias else ("weight",):
+                yield m, kind, getattr(m, f"mu_{kind}"), getattr(m, f"rho_{kind}")
+
+    def usable(self, ctx):
+        if ctx is None or ctx.eps is not None or ctx.nsets != 1 or not self.leaves:
+            return False
+        m0 = self.leaves[0]
+        return all(m.training and not m.deterministic and m.decay == m0.decay and m.step == m0.step for m in self.leaves)
+
+    def _signature(self):
+        sig = []
+        for m, kind, mu, rho in self._tensors():
+            sig += [mu.data_ptr(), rho.data_ptr(), ag.grad_of(mu).data_ptr(), ag.grad_of(rho).data_ptr(),
+                    getattr(m, f"prior_mu_{kind}").data_ptr(), getattr(m, f"prior_rho_{kind}").data_ptr()]
+        return tuple(sig)
+
+    def _build(self):
+        if torch.cuda.is_current_stream_capturing():
+            raise BemNativeError("BayesBank: its tables cannot be (re)built while a HIP graph is being captured")
+        dev = self.leaves[0].mu_weight.device
+        rows, blks, off = [], [], 0
+        items = list(self._tensors())
+        for s_, (m, kind, mu, rho) in enumerate(items):
+            n = mu.numel()
+            inv_n = int.from_bytes(torch.tensor(1.0 / n, dtype=torch.float32).numpy().tobytes(), "little")
+            rows.append([mu.data_ptr(), rho.data_ptr(), ag.grad_of(mu).data_ptr(), ag.grad_of(rho).data_ptr(), off, n, m._draw_order[kind], inv_n])
+            blks += [[s_, b] for b in range(0, n, 1024)]
+            off += (n + 3) // 4 * 4
+        self.total, self.nblk = off, len(blks)
+        pm, pr = torch.empty(off, device=dev), torch.empty(off, device=dev)
+        self.w, self.eps, self.gw = torch.zeros(off, device=dev), torch.zeros(off, device=dev), torch.zeros(off, device=dev)
+        self.views = []
+        for (m, kind, mu, rho), r in zip(items, rows):
+            o, n = r[4], r[5]
+            with torch.no_grad():
+                pm[o:o + n].copy_(getattr(m, f"prior_mu_{kind}").reshape(-1))
+                pr[o:o + n].copy_(getattr(m, f"prior_rho_{kind}").reshape(-1))
+            setattr(m, f"prior_mu_{kind}", pm[o:o + n].view(mu.shape))
+            setattr(m, f"prior_rho_{kind}", pr[o:o + n].view(mu.shape))
+            wv = self.w[o:o + n].view(mu.shape)
+            wv.grad = self.gw[o:o + n].view(mu.shape)
+            self.views.append((m, kind, wv, self.eps[o:o + n].view((1,) + tuple(mu.shape))))
+        self.pm, self.pr = pm, pr
+        self.segs = torch.tensor(rows, dtype=torch.int64).to(dev)
+        self.blks = torch.tensor(blks, dtype=torch.int32).to(dev)
+        self.sig = self._signature()
+
+    def sample(self, ctx, step, state=None):
+        """One launch: every leaf's prior EMA, eps and weight sample for this forward.  The leaves are handed their views and marked as
+        sampled for ``step``; their own _train_sample() then has nothing left to do."""
+        if self.sig != self._signature():
+            self._build()                                # a parameter, gradient or prior buffer moved (optimizer created, net.to(...))
+        m0 = self.leaves[0]
+        decay = lambda: min(m0.decay, (1 + m0.step) / (10 + m0.step))
+        d_dev = state.slot(decay) if state is not None else None
+        base = (ctx.rank << 44) | (ctx.epoch << 20) | ctx.counter
+        ops.bnn_bank_sample(self, decay(), d_dev, ctx.seed, base, ctx.epoch_dev)
+        ctx.counter += len(self.views)
+        for m, kind, wv, ev in self.views:
+            if kind == "weight":
+                m._ws, m._eps_w, m._bs, m._eps_b = wv, ev, None, None
+                m._sample_owner = step
+                step.leaves.append(m)
+                if state is None:
+                    m.step += 1
+                else:
+                    state.on_advance(m._count_step)
+            else:
+                m._bs, m._eps_b = wv, ev
+        step.bank = self
 
 
 class Conv2dReparameterization(_BayesBase):

@@ -64,9 +64,14 @@ SIGNATURES = {
     "bem_pw_packed_elems": [I, I],
     "bem_pw_gemm_x6_f32": [ctypes.POINTER(PwArgs), P],
     "bem_pack_pw_weight_x6": [P, P, I, I, I, P],
+    "bem_pack_pw_weight_x6_strided": [P, P, I, I, I, I64, I64, I64, P],
     "bem_pw_x6_packed_elems": [I, I],
     "bem_bnn_sample_pack_x6": [P, P, P, P, I, I, I, U64, U64, P, I, P],
     "bem_store_words": [P, P, I, P],
+    "bem_bnn_bank_sample_f32": [P, P, I, P, P, P, P, P, F, P, U64, U64, P, P],
+    "bem_bnn_bank_kl_f32": [P, P, I, P, P, P, P],
+    "bem_bnn_bank_kl_bwd_f32": [P, P, I, P, P, P, P],
+    "bem_bnn_bank_reparam_bwd_f32": [P, P, I, P, P, P],
     "bem_row_scale_f32": [P, P, P, I, I, P],
     "bem_se_gate_f32": [P, P, P, P, I, I, I, P],
     "bem_spatial_attention_f32": [P, P, P, P, P, I, I, I, I, I, P],

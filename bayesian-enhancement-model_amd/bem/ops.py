@@ -192,12 +192,18 @@ def packed_elems(M: int, K: int, x6: bool = False) -> int:
 def pack_pw_weight(W, x6=None):
     """(M,K) or (nsets,M,K) natural weights -> packed MFMA operand order, shape (nsets, packed).
     x6: None = module default (USE_X6), False = f32 operands (also what the MFMA convolution consumes)."""
-    _chk(W, "W")
     if W.dim() == 2:
         W = W[None]
     ns, M, K = W.shape
     x6 = USE_X6 if x6 is None else x6
     out = torch.empty(ns, packed_elems(M, K, x6), device=W.device, dtype=W.dtype)
+    if x6 and not W.is_contiguous():            # a transposed / sliced view (W^T of an input-gradient GEMM): packed where it lies
+        if not W.is_cuda or W.dtype != torch.float32:
+            raise native.BemNativeError("pack_pw_weight: a float32 CUDA/HIP tensor")
+        check(lib().bem_pack_pw_weight_x6_strided(_p(W), _p(out), ns, M, K, W.stride(0), W.stride(1), W.stride(2), _stream()), "pack_pw_weight")
+        out._bem_mk = (M, K)
+        return out
+    _chk(W, "W")
     fn = lib().bem_pack_pw_weight_x6 if x6 else lib().bem_pack_pw_weight_f32
     check(fn(_p(W), _p(out), ns, M, K, _stream()), "pack_pw_weight")
     out._bem_mk = (M, K)          # the x6 size only pins ceil(K/16): keep the exact logical shape for pw_gemm's check
@@ -641,6 +647,25 @@ def bnn_prior_ema_(prior_mu, prior_rho, mu, rho, decay, decay_dev=None):
     if not (prior_mu.shape == prior_rho.shape == mu.shape == rho.shape):
         raise ValueError("bnn_prior_ema_: shapes differ")
     check(lib().bem_bnn_prior_ema_f32(_p(prior_mu), _p(prior_rho), _p(mu), _p(rho), float(decay), _p(decay_dev), mu.numel(), _stream()), "bnn_prior_ema")
+
+
+def bnn_bank_sample(bank, decay, decay_dev, seed, stream_base, stream_add):
+    check(lib().bem_bnn_bank_sample_f32(_p(bank.segs), _p(bank.blks), bank.nblk, _p(bank.pm), _p(bank.pr), _p(bank.w), _p(bank.eps), _p(bank.gw),
+                                        float(decay), _p(decay_dev), seed, stream_base, _p(stream_add), _stream()), "bnn_bank_sample")
+
+
+def bnn_bank_kl_(bank, out):
+    _chk(out, "out")
+    check(lib().bem_bnn_bank_kl_f32(_p(bank.segs), _p(bank.blks), bank.nblk, _p(bank.pm), _p(bank.pr), _p(out), _stream()), "bnn_bank_kl")
+
+
+def bnn_bank_kl_bwd_(bank, g):
+    _chk(g, "g")
+    check(lib().bem_bnn_bank_kl_bwd_f32(_p(bank.segs), _p(bank.blks), bank.nblk, _p(bank.pm), _p(bank.pr), _p(g), _stream()), "bnn_bank_kl_bwd")
+
+
+def bnn_bank_reparam_bwd_(bank):
+    check(lib().bem_bnn_bank_reparam_bwd_f32(_p(bank.segs), _p(bank.blks), bank.nblk, _p(bank.gw), _p(bank.eps), _stream()), "bnn_bank_reparam_bwd")
 
 
 def bnn_kl_(mu, rho, prior_mu, prior_rho, out):

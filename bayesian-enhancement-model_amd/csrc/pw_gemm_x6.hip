@@ -525,7 +525,8 @@ __global__ __launch_bounds__(256, 2) void pw_x6_stream_kernel(PwX k) {
 }
 
 // natural (nsets, M, K) f32 -> (nsets, MT, KB, 3, 64) 16-byte vectors of bf16 limbs
-__global__ void pack_x6_kernel(const float* __restrict__ W, u32x4* __restrict__ Wp, int M, int K, int MT, int KB, int64_t total) {
+__global__ void pack_x6_kernel(const float* __restrict__ W, u32x4* __restrict__ Wp, int M, int K, int MT, int KB, int64_t total,
+                               int64_t ss, int64_t rs, int64_t cs) {      // element strides of W over (set, row, k): transposed / sliced views pack in place
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int lane = (int)(i & 63);
@@ -535,7 +536,7 @@ __global__ void pack_x6_kernel(const float* __restrict__ W, u32x4* __restrict__ 
     const int row = mt * 32 + (lane & 31), k0 = kb * 16 + (lane >> 5) * 8;
     float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (row < M && k0 + e < K) ? W[(set * M + row) * K + k0 + e] : 0.f;
+    for (int e = 0; e < 8; ++e) v[e] = (row < M && k0 + e < K) ? W[set * ss + row * rs + (k0 + e) * cs] : 0.f;
     u32x4 h, m, l;
     split8(v, h, m, l);
     u32x4* o = Wp + ((set * MT + mt) * KB + kb) * 3 * 64 + lane;
@@ -603,15 +604,21 @@ extern "C" int64_t bem_pw_x6_packed_elems(int M, int K) {       // in floats (4 
     return (int64_t)cdiv(M, 32) * cdiv(K, 16) * 3 * 64 * 4;
 }
 
-extern "C" int bem_pack_pw_weight_x6(const float* W, float* Wp, int nsets, int M, int K, void* stream) {
+extern "C" int bem_pack_pw_weight_x6_strided(const float* W, float* Wp, int nsets, int M, int K, int64_t set_stride, int64_t row_stride,
+                                             int64_t col_stride, void* stream) {
     BEM_REQUIRE(W && Wp, "pack_pw_weight_x6: null tensor");
-    BEM_REQUIRE(nsets >= 0 && M > 0 && K > 0, "pack_pw_weight_x6: bad shape");
+    BEM_REQUIRE(nsets >= 0 && M > 0 && K > 0 && set_stride >= 0 && row_stride >= 0 && col_stride >= 0, "pack_pw_weight_x6: bad shape / strides");
     BEM_REQUIRE(((uintptr_t)Wp & 15) == 0, "pack_pw_weight_x6: output must be 16-byte aligned");
     if (nsets == 0) return BEM_OK;
     const int MT = cdiv(M, 32), KB = cdiv(K, 16);
     const int64_t total = (int64_t)nsets * MT * KB * 64;
-    pack_x6_kernel<<<(unsigned)cdiv64(total, 256), 256, 0, (hipStream_t)stream>>>(W, reinterpret_cast<u32x4*>(Wp), M, K, MT, KB, total);
+    pack_x6_kernel<<<(unsigned)cdiv64(total, 256), 256, 0, (hipStream_t)stream>>>(W, reinterpret_cast<u32x4*>(Wp), M, K, MT, KB, total, set_stride,
+                                                                                 row_stride, col_stride);
     return bem_check_launch("pack_pw_weight_x6");
+}
+
+extern "C" int bem_pack_pw_weight_x6(const float* W, float* Wp, int nsets, int M, int K, void* stream) {
+    return bem_pack_pw_weight_x6_strided(W, Wp, nsets, M, K, (int64_t)M * K, K, 1, stream);
 }
 
 extern "C" int bem_pw_gemm_x6_f32(const bem_pw_args* a, void* stream) {

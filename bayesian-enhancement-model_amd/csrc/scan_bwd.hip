@@ -208,6 +208,50 @@ __global__ __launch_bounds__(NT) void ss2d_scan_bwd_kernel(
 }
 
 
+// Planes of at most 256 pixels (Stage I: 8x8 .. 2x2 under 128x128 crops): one wavefront holds a whole row, and what costs is the atomic
+// traffic of every channel adding its (R + 2) x L x_dbl gradients onto the same addresses.  A workgroup of one wavefront takes CBS channels
+// of an (orientation, image) one after the other, collects their x_dbl gradients in LDS (both directions: 2 (R + 2) L floats) and adds
+// the sums to memory once -- CBS times fewer global atomics.
+template <int CBS>
+__global__ __launch_bounds__(64) void ss2d_scan_bwd_small_kernel(
+    const float* __restrict__ x0, const float* __restrict__ x1, const float* __restrict__ xd0, const float* __restrict__ xd1,
+    const float* __restrict__ dy0, const float* __restrict__ dy1, const float* __restrict__ dtw, const float* __restrict__ dtb,
+    const float* __restrict__ A, const float* __restrict__ Ds, float* __restrict__ dx0, float* __restrict__ dx1,
+    float* __restrict__ dxd0, float* __restrict__ dxd1, float* __restrict__ dAlog, float* __restrict__ dDs, float* __restrict__ ddtw,
+    float* __restrict__ ddtb, int Bn, int C, int L, int R, int64_t xbs0, int64_t xbs1) {
+    __shared__ float agg[2];
+    __shared__ float red[1];
+    __shared__ float cs[SB_MAXCH];
+    __shared__ float nb[3];
+    __shared__ float accw[16];
+    __shared__ float dacc[2 * 18 * 256];
+    const int G = (C + CBS - 1) / CBS;
+    const int wi = blockIdx.x;
+    const int g = wi % G, b = (wi / G) % Bn, o = wi / (G * Bn);
+    const int nacc = 2 * (R + 2) * L;
+    for (int i = threadIdx.x; i < nacc; i += 64) dacc[i] = 0.f;
+    __syncthreads();
+    const float* xd = o ? xd1 + (int64_t)b * xbs1 : xd0 + (int64_t)b * xbs0;
+    const int kf = o, kr = o + 2;
+    for (int ch = 0; ch < CBS; ++ch) {
+        const int c = g * CBS + ch;
+        if (c >= C) break;                                                   // uniform
+        const int64_t row = ((int64_t)b * C + c) * L;
+        const float* xr = (o ? x1 : x0) + row;
+        const float* dyr = (o ? dy1 : dy0) + row;
+        float* dxr = (o ? dx1 : dx0) + row;
+        ss2d_dir_bwd<64, 4, false>(xr, dyr, xd, dacc, dxr, dtw + ((int64_t)kf * C + c) * R, dtb[kf * C + c], A[kf * C + c], Ds[kf * C + c], L, R,
+                                   true, agg, red, cs, nb, accw, dAlog + kf * C + c, dDs + kf * C + c, ddtb + kf * C + c,
+                                   ddtw + ((int64_t)kf * C + c) * R);
+        ss2d_dir_bwd<64, 4, true>(xr, dyr, xd + (int64_t)(R + 2) * L, dacc + (R + 2) * L, dxr, dtw + ((int64_t)kr * C + c) * R,
+                                  dtb[kr * C + c], A[kr * C + c], Ds[kr * C + c], L, R, false, agg, red, cs, nb, accw, dAlog + kr * C + c,
+                                  dDs + kr * C + c, ddtb + kr * C + c, ddtw + ((int64_t)kr * C + c) * R);
+    }
+    __syncthreads();
+    float* dxd = (o ? dxd1 : dxd0) + (int64_t)b * 2 * (R + 2) * L;
+    for (int i = threadIdx.x; i < nacc; i += 64) atomicAdd(dxd + i, dacc[i]);
+}
+
 // ------------------------------------------------------------------------------------------------------------------------
 // Whole-row, channel-blocked form for L == NT * 4 * T (the planes of 256x256 / 128x128 inputs): the structure of the forward's
 // ss2d_scan_rows_kernel.  A workgroup owns CB channels of one (orientation, image); tiles are the outer loop, channels the
@@ -499,8 +543,12 @@ extern "C" int bem_ss2d_scan_bwd_f32(const float* x0, const float* x1, const flo
 #undef BEM_BWD_ROWS
     }
     const int grid = C * B * 2;
-    if (L <= 256)         // Stage-I planes (8x8 .. 2x2 of 128x128 crops): one wavefront per row
+    if (L <= 32)          // 4x4 and 2x2 planes: a workgroup per channel (the atomics are few, the channel loop below would only serialise)
         ss2d_scan_bwd_kernel<64, 4><<<grid, 64, 0, s>>>(x0, x1, xd0, xd1, dy0, dy1, dtw, dtb, A, Ds, dx0, dx1, dxd0, dxd1, dAlog, dDs, ddtw, ddtb, B, C, L, R, xbs0, xbs1);
+    else if (L <= 256) {  // 8x8 .. 16x16 planes: one wavefront per row, 4 channels per workgroup (181 -> 114 us at L = 64, C = 160, B = 8)
+        constexpr int CBS = 4;
+        ss2d_scan_bwd_small_kernel<CBS><<<cdiv(C, CBS) * B * 2, 64, 0, s>>>(x0, x1, xd0, xd1, dy0, dy1, dtw, dtb, A, Ds, dx0, dx1, dxd0, dxd1, dAlog, dDs, ddtw, ddtb, B, C, L, R, xbs0, xbs1);
+    }
     else if (L <= 1024)
         ss2d_scan_bwd_kernel<256, 4><<<grid, 256, 0, s>>>(x0, x1, xd0, xd1, dy0, dy1, dtw, dtb, A, Ds, dx0, dx1, dxd0, dxd1, dAlog, dDs, ddtw, ddtb, B, C, L, R, xbs0, xbs1);
     else

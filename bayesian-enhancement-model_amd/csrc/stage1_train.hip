@@ -72,6 +72,95 @@ __global__ void reparam_bwd_kernel(const float* __restrict__ gw, const float* __
     drho[i] += g * eps[i] * sigmoid_ref(rho[i]);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The same four steps for ALL Bayesian tensors of a net in one launch each (60 leaves / 90 tensors in the shipped Stage-I net: per tensor
+// they are ~630 launches of a few hundred elements per training step).  A "bank" describes the tensors as segments of flat arenas:
+//   seg[s] = { mu, rho, dmu, drho (device pointers of the parameter / its gradient buffer), off (first element in the arenas, a
+//              multiple of 4), n (elements), stream counter (low bits of the tensor's Philox stream id) }
+//   blk[b] = { segment, first element of the block inside the segment }         one workgroup = 1024 consecutive elements of one segment
+//   arenas: prior_mu, prior_rho, w (the sample), eps (its draw), gw (the sample's gradient, zeroed by the sampling launch)
+// Arithmetic per element is that of prior_ema_kernel / randn_kernel / bnn_sample_kernel / kl_kernel / kl_bwd_kernel / reparam_bwd_kernel.
+// ------------------------------------------------------------------------------------------------------------------------
+struct bank_seg { float* mu; float* rho; float* dmu; float* drho; int64_t off; int64_t n; uint64_t counter; float inv_n; int pad; };
+static_assert(sizeof(bank_seg) == 8 * 8, "bank_seg is eight 64-bit words (bem.modules.BayesBank builds it as an int64 table)");
+struct bank_blk { int32_t seg; int32_t first; };
+constexpr int BANK_EPT = 4;            // elements per thread
+
+__global__ __launch_bounds__(NT) void bank_sample_kernel(const bank_seg* __restrict__ segs, const bank_blk* __restrict__ blks,
+                                                         float* __restrict__ pmu, float* __restrict__ prho, float* __restrict__ w,
+                                                         float* __restrict__ eps, float* __restrict__ gw, float decay,
+                                                         const float* __restrict__ decay_dev, uint64_t seed, uint64_t stream_base,
+                                                         const uint64_t* __restrict__ stream_add) {
+    const bank_blk bk = blks[blockIdx.x];
+    const bank_seg sg = segs[bk.seg];
+    if (decay_dev) decay = decay_dev[0];
+    uint64_t sid = stream_base + sg.counter;
+    if (stream_add) sid += stream_add[0];
+#pragma unroll
+    for (int q = 0; q < BANK_EPT; ++q) {
+        const int64_t i = (int64_t)bk.first + q * NT + threadIdx.x;
+        if (i >= sg.n) break;
+        const int64_t a = sg.off + i;
+        const float m = sg.mu[i], r = sg.rho[i];
+        pmu[a] = decay * pmu[a] + (1.f - decay) * m;
+        prho[a] = decay * prho[a] + (1.f - decay) * r;
+        const float e = philox_normal(i, seed, sid);
+        eps[a] = e;
+        w[a] = m + log1pf(expf(r)) * e;
+        gw[a] = 0.f;
+    }
+}
+
+__global__ __launch_bounds__(NT) void bank_kl_kernel(const bank_seg* __restrict__ segs, const bank_blk* __restrict__ blks,
+                                                     const float* __restrict__ pmu, const float* __restrict__ prho, float* __restrict__ out) {
+    __shared__ float sh[4];
+    const bank_blk bk = blks[blockIdx.x];
+    const bank_seg sg = segs[bk.seg];
+    float acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < BANK_EPT; ++q) {
+        const int64_t i = (int64_t)bk.first + q * NT + threadIdx.x;
+        if (i < sg.n) {
+            const float sq = softplus_ref(sg.rho[i]), sp = softplus_ref(prho[sg.off + i]), d = sg.mu[i] - pmu[sg.off + i];
+            acc += logf(sp) - logf(sq) + (sq * sq + d * d) / (2.f * sp * sp) - 0.5f;
+        }
+    }
+    const float s = block_sum(acc, sh);
+    if (threadIdx.x == 0) atomicAdd(out, s * sg.inv_n);
+}
+
+__global__ __launch_bounds__(NT) void bank_kl_bwd_kernel(const bank_seg* __restrict__ segs, const bank_blk* __restrict__ blks,
+                                                         const float* __restrict__ pmu, const float* __restrict__ prho,
+                                                         const float* __restrict__ g) {
+    const bank_blk bk = blks[blockIdx.x];
+    const bank_seg sg = segs[bk.seg];
+    const float s = g[0] * sg.inv_n;
+#pragma unroll
+    for (int q = 0; q < BANK_EPT; ++q) {
+        const int64_t i = (int64_t)bk.first + q * NT + threadIdx.x;
+        if (i >= sg.n) break;
+        const float r = sg.rho[i];
+        const float sq = softplus_ref(r), sp = softplus_ref(prho[sg.off + i]);
+        const float isp2 = 1.f / (sp * sp);
+        sg.dmu[i] += s * (sg.mu[i] - pmu[sg.off + i]) * isp2;
+        sg.drho[i] += s * (sq * isp2 - 1.f / sq) * sigmoid_ref(r);
+    }
+}
+
+__global__ __launch_bounds__(NT) void bank_reparam_bwd_kernel(const bank_seg* __restrict__ segs, const bank_blk* __restrict__ blks,
+                                                              const float* __restrict__ gw, const float* __restrict__ eps) {
+    const bank_blk bk = blks[blockIdx.x];
+    const bank_seg sg = segs[bk.seg];
+#pragma unroll
+    for (int q = 0; q < BANK_EPT; ++q) {
+        const int64_t i = (int64_t)bk.first + q * NT + threadIdx.x;
+        if (i >= sg.n) break;
+        const float g = gw[sg.off + i];
+        sg.dmu[i] += g;
+        sg.drho[i] += g * eps[sg.off + i] * sigmoid_ref(sg.rho[i]);
+    }
+}
+
 // fea * (1 - w) + token * w,  w = mask (B,H,W) broadcast over channels (UNet_arch.py:463-466)
 __global__ void mask_token_kernel(const float* __restrict__ fea, const float* __restrict__ mask, const float* __restrict__ token,
                                   float* __restrict__ out, int C, int L, int64_t total) {
@@ -187,6 +276,37 @@ extern "C" int bem_bnn_prior_ema_f32(float* prior_mu, float* prior_rho, const fl
     if (n == 0) return BEM_OK;
     prior_ema_kernel<<<(unsigned)((n + NT - 1) / NT), NT, 0, (hipStream_t)stream>>>(prior_mu, prior_rho, mu, rho, decay, decay_dev, n);
     return bem_check_launch("bnn_prior_ema");
+}
+
+// Bank forms (see bank_seg above): segs = nseg x 8 int64 words, blks = nblk x 2 int32 words, both in device memory.
+extern "C" int bem_bnn_bank_sample_f32(const void* segs, const void* blks, int nblk, float* prior_mu, float* prior_rho, float* w, float* eps,
+                                       float* gw, float decay, const float* decay_dev, uint64_t seed, uint64_t stream_base,
+                                       const uint64_t* stream_add, void* stream) {
+    BEM_REQUIRE(segs && blks && prior_mu && prior_rho && w && eps && gw && nblk > 0, "bnn_bank_sample: bad arguments");
+    BEM_REQUIRE(decay_dev || (decay >= 0.f && decay <= 1.f), "bnn_bank_sample: decay outside [0, 1]");
+    bank_sample_kernel<<<nblk, NT, 0, (hipStream_t)stream>>>((const bank_seg*)segs, (const bank_blk*)blks, prior_mu, prior_rho, w, eps, gw, decay,
+                                                            decay_dev, seed, stream_base, stream_add);
+    return bem_check_launch("bnn_bank_sample");
+}
+
+extern "C" int bem_bnn_bank_kl_f32(const void* segs, const void* blks, int nblk, const float* prior_mu, const float* prior_rho, float* out,
+                                   void* stream) {
+    BEM_REQUIRE(segs && blks && prior_mu && prior_rho && out && nblk > 0, "bnn_bank_kl: bad arguments");
+    bank_kl_kernel<<<nblk, NT, 0, (hipStream_t)stream>>>((const bank_seg*)segs, (const bank_blk*)blks, prior_mu, prior_rho, out);
+    return bem_check_launch("bnn_bank_kl");
+}
+
+extern "C" int bem_bnn_bank_kl_bwd_f32(const void* segs, const void* blks, int nblk, const float* prior_mu, const float* prior_rho, const float* g,
+                                       void* stream) {
+    BEM_REQUIRE(segs && blks && prior_mu && prior_rho && g && nblk > 0, "bnn_bank_kl_bwd: bad arguments");
+    bank_kl_bwd_kernel<<<nblk, NT, 0, (hipStream_t)stream>>>((const bank_seg*)segs, (const bank_blk*)blks, prior_mu, prior_rho, g);
+    return bem_check_launch("bnn_bank_kl_bwd");
+}
+
+extern "C" int bem_bnn_bank_reparam_bwd_f32(const void* segs, const void* blks, int nblk, const float* gw, const float* eps, void* stream) {
+    BEM_REQUIRE(segs && blks && gw && eps && nblk > 0, "bnn_bank_reparam_bwd: bad arguments");
+    bank_reparam_bwd_kernel<<<nblk, NT, 0, (hipStream_t)stream>>>((const bank_seg*)segs, (const bank_blk*)blks, gw, eps);
+    return bem_check_launch("bnn_bank_reparam_bwd");
 }
 
 extern "C" int bem_bnn_kl_f32(const float* mu, const float* rho, const float* prior_mu, const float* prior_rho, int64_t n, float* out,

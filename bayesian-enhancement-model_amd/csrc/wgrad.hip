@@ -185,7 +185,7 @@ int launch_wgrad_t(WgK k, hipStream_t s) {
     const int target = std::max(1, 512 / (ny * nz));
     // ... unless the whole problem is a handful of chunks (Stage I: 8x8 .. 2x2 planes): there one workgroup walking them one after the
     // other is pure latency, and the few extra atomics cost nothing
-    k.chunks_per_wg = std::max(k.total_chunks >= 256 ? 8 : 2, cdiv(k.total_chunks, target));
+    k.chunks_per_wg = std::max(k.total_chunks >= 256 ? 8 : (k.total_chunks >= 32 ? 2 : 1), cdiv(k.total_chunks, target));
     const int nx = cdiv(k.total_chunks, k.chunks_per_wg);
     const size_t shm = (size_t)(MC + NC) * LDR * sizeof(float);
     static_assert((MC + NC) * LDR * sizeof(float) <= 64 * 1024, "dynamic LDS above 64 KiB needs hipFuncSetAttribute");

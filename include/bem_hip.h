@@ -139,6 +139,10 @@ int64_t bem_pw_packed_elems(int M, int K);
  * aligned.  LayerNorm prologue for K <= 160. */
 int bem_pw_gemm_x6_f32(const bem_pw_args* a, void* stream);
 int bem_pack_pw_weight_x6(const float* W, float* Wp, int nsets, int M, int K, void* stream);
+/* The same from a strided view (element strides over set, row, k): the transposed weight of an input-gradient GEMM (W^T = strides (., 1, K))
+ * or a column block of a concatenated weight is packed where it lies, without a contiguous copy. */
+int bem_pack_pw_weight_x6_strided(const float* W, float* Wp, int nsets, int M, int K, int64_t set_stride, int64_t row_stride,
+                                  int64_t col_stride, void* stream);
 int64_t bem_pw_x6_packed_elems(int M, int K);
 /* bem_bnn_sample_f32 (below) and bem_pack_pw_weight_x6 in one pass for the weights of a Bayesian 1x1 layer: nsets weight
  * sets w = mu + log1p(exp(rho)) * eps written straight in x6 operand order; eps (nsets, M, K) injected or NULL = the
@@ -431,6 +435,20 @@ int bem_store_words(void* dst, const void* host_words, int n, void* stream);
  * by value or (decay_dev != NULL) as one float in device memory that the kernel reads -- the form a captured step uses. */
 int bem_bnn_prior_ema_f32(float* prior_mu, float* prior_rho, const float* mu, const float* rho, float decay, const float* decay_dev,
                           int64_t n, void* stream);
+
+/* The four Bayesian training steps (prior EMA + eps draw + sample, KL, KL backward, reparameterisation backward) for ALL Bayesian
+ * tensors of a net in one launch each.  segs: nseg x 8 64-bit words {mu, rho, dmu, drho pointers; first element in the arenas
+ * (multiple of 4); elements n; stream counter; float 1/n in the low half of the last word}; blks: nblk x {int32 segment, int32 first
+ * element}: one workgroup = 1024 consecutive elements of one segment.  prior_mu / prior_rho / w / eps / gw are flat arenas indexed by
+ * segment offset + element.  sample: prior = decay prior + (1 - decay) param; eps = the Philox draw bem_randn_f32 makes for
+ * (seed, stream_base + counter [+ *stream_add]); w = mu + log1p(exp(rho)) eps; gw = 0.  kl / kl_bwd / reparam_bwd: as the per-tensor
+ * entry points below, gradients accumulated through the dmu / drho pointers.  Replaces conv.py:84-112 + tools.py:76-84 over a net. */
+int bem_bnn_bank_sample_f32(const void* segs, const void* blks, int nblk, float* prior_mu, float* prior_rho, float* w, float* eps, float* gw,
+                            float decay, const float* decay_dev, uint64_t seed, uint64_t stream_base, const uint64_t* stream_add, void* stream);
+int bem_bnn_bank_kl_f32(const void* segs, const void* blks, int nblk, const float* prior_mu, const float* prior_rho, float* out, void* stream);
+int bem_bnn_bank_kl_bwd_f32(const void* segs, const void* blks, int nblk, const float* prior_mu, const float* prior_rho, const float* g,
+                            void* stream);
+int bem_bnn_bank_reparam_bwd_f32(const void* segs, const void* blks, int nblk, const float* gw, const float* eps, void* stream);
 
 /* out[0] += mean( log sp - log sq + (sq^2 + (mu - prior_mu)^2) / (2 sp^2) - 0.5 ), s = log1p(exp(rho))  (base_layer.py:26-40 kl_div). */
 int bem_bnn_kl_f32(const float* mu, const float* rho, const float* prior_mu, const float* prior_rho, int64_t n, float* out, void* stream);

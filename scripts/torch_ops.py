@@ -1,5 +1,6 @@
 """Which torch-side ops (copies, cats, fills ...) does one eval step still launch, and from where?
-   python scripts/torch_ops.py   -> table by op, then the Python call sites of every aten::copy_ / cat / fill / index op of one step."""
+   python scripts/torch_ops.py   -> table by op, then the Python call sites of every aten::copy_ / cat / fill / index op of one step.
+   python scripts/torch_ops.py train1   -> the same for one Stage-I training step launched kernel by kernel (in its captured form every such op is a graph node)."""
 import collections, os, sys, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "bayesian-enhancement-model_amd"))
@@ -7,9 +8,30 @@ import torch
 from torch.profiler import profile, ProfilerActivity
 from torch.utils._python_dispatch import TorchDispatchMode
 from bem.pipeline import BEMPipeline, build_nets, synthetic_pair
-net1, net2 = build_nets(device="cuda")
-pipe = BEMPipeline(net1, net2)
-lq, gt = synthetic_pair((8, 3, 256, 256), device="cuda")
+if len(sys.argv) > 1 and sys.argv[1] == "train1":
+    os.environ["BEM_STAGE1_GRAPH"] = "0"
+    from basicsr.models import build_model
+    from basicsr.utils.options import parse as parse_opt
+    from bem import ops
+    opt = parse_opt(os.path.join(ROOT, "bayesian-enhancement-model_amd", "Options", "CG_UNet_LOLv1.yml"), is_train=True)
+    opt["dist"], opt["rank"], opt["world_size"] = False, 0, 1
+    torch.manual_seed(100)
+    model = build_model(opt)
+    lq, gt = synthetic_pair((8, 3, 128, 128), device="cuda")
+    batch = dict(lq_down=ops.resize_down(lq, 16), gt=gt, gt_down=ops.resize_down(gt, 16), mask=(torch.rand(8, 8, 8) < 0.4).float().cuda())
+    it = [0]
+
+    class _P:
+        def enhance(self, *a, **k):
+            it[0] += 1
+            model.update_learning_rate(it[0], warmup_iter=-1)
+            model.feed_train_data(batch)
+            model.optimize_parameters(it[0])
+    pipe = _P()
+else:
+    net1, net2 = build_nets(device="cuda")
+    pipe = BEMPipeline(net1, net2)
+    lq, gt = synthetic_pair((8, 3, 256, 256), device="cuda")
 for i in range(2):
     pipe.enhance(lq, gt, 8, seed=i, sync=False)
 torch.cuda.synchronize()

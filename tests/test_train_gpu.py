@@ -650,6 +650,32 @@ def test_training_driver_save_resume_reproduces_the_run(dev, tmp_path, yml, firs
     assert (st / f"{(total // 3) * 3}.state").is_file()
 
 
+def test_stage1_bayes_bank_equals_the_per_leaf_steps(dev, tmp_path, monkeypatch):
+    """The Bayesian bookkeeping of a Stage-I training iteration for all 90 Bayesian tensors of the net in one launch each (BayesBank over
+    bem_bnn_bank_*: prior EMA + eps draw + weight sample, KL, KL backward, reparameterisation backward; conv.py:84-112, tools.py:76-84)
+    against the same 6 iterations done tensor by tensor (BEM_BAYES_BANK=0), both launched kernel by kernel.  The bank draws every tensor
+    from the Philox stream the per-leaf forward uses for it, so the two runs see the same weight samples: parameters, EMA priors and
+    losses agree to the noise of the atomically reduced gradients."""
+    monkeypatch.setenv("BEM_STAGE1_GRAPH", "0")
+    monkeypatch.setenv("BEM_BAYES_BANK", "0")
+    a, ia = _run_driver(tmp_path / "A", "CG_UNet_LOLv1.yml", [], 6)
+    assert a.net_g.__dict__.get("_bayes_bank") is None
+    monkeypatch.setenv("BEM_BAYES_BANK", "1")
+    b, ib = _run_driver(tmp_path / "B", "CG_UNet_LOLv1.yml", [], 6)
+    bank = b.net_g.__dict__.get("_bayes_bank")
+    assert bank is not None and bank.ready() and len(bank.views) == sum(2 if m.bias else 1 for m in bank.leaves) >= 30
+    pa, pb = dict(a.net_g.named_parameters()), dict(b.net_g.named_parameters())
+    worst = max(float((pa[k].detach() - pb[k].detach()).abs().max()) for k in pa)
+    assert worst <= 4e-5, worst
+    for (ka, ma), (kb, mb) in zip(a.net_g.named_modules(), b.net_g.named_modules()):
+        if hasattr(ma, "kl_terms"):
+            assert ma.step == mb.step == 6
+            for ta, tb in zip(ma.kl_terms(), mb.kl_terms()):
+                assert float((ta[2] - tb[2]).abs().max()) <= 4e-5 and float((ta[3] - tb[3]).abs().max()) <= 4e-5, ka
+    assert abs(float(a.log_dict["l_kl"]) - float(b.log_dict["l_kl"])) <= 1e-4 * max(1.0, abs(float(a.log_dict["l_kl"])))
+    assert abs(float(a.log_dict["l_pix"]) - float(b.log_dict["l_pix"])) <= 1e-4
+
+
 def test_stage1_captured_step_equals_the_launched_one(dev, tmp_path, monkeypatch):
     """the Stage-I training step replayed from a HIP graph (condition_generator_model.py:176-218 -- zero_grad,
     forward with the MIM mask, KL + L1, backward, clip, AdamW) against the same 8 iterations launched kernel by kernel
