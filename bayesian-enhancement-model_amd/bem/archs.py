@@ -763,11 +763,21 @@ class Network(nn.Module):
         with torch.no_grad(), sampling(ctx):
             set_module_paths(self)
             x = x.contiguous()
+            bank = None
+            if ctx.eps is None and ctx.nsets > 1 and os.environ.get("BEM_EVAL_SAMPLE_BANK", "1") != "0":
+                from .modules import EvalSampleBank
+                bank = self.__dict__.get("_eval_bank")
+                if bank is None:
+                    bank = self.__dict__["_eval_bank"] = EvalSampleBank(self)
+                ctx.counter0 = ctx.counter
+                if bank.usable(ctx):
+                    bank.sample(ctx)                     # all leaves' weight sets in one launch; the first Philox forward goes leaf by leaf
             fea0 = self.first_conv(x)
             dec = self.subnets[0](fea0)
             # proj(fea0 + dec) = proj_nobias(fea0) + proj(dec)   (UNet_arch.py:361,470-472; conv is linear)
             base = ops.conv2d(fea0, self.proj.weight.detach(), None, pad=1)
             out = self.proj(dec, res1=base)
+            ctx.bank = None
         return [x, out]
 
     def _forward_train(self, x, mask, ctx):

@@ -72,6 +72,8 @@ class SampleCtx:
         # epoch_dev: one int64 on the device holding ``epoch << 20``, added to the stream ids by the sampling kernels; the ids handed out
         # here then carry epoch 0.  A captured step (HIP graph) replays with whatever epoch the host wrote there last.
         self.epoch_dev = epoch_dev
+        self.bank = None                     # EvalSampleBank whose one launch made this forward's draws (set by Network.forward)
+        self.counter0 = 0                    # value of ``counter`` when the forward began (the leaves record relative stream numbers)
         if epoch_dev is not None:
             epoch = 0
         if epoch is None:
@@ -293,6 +295,10 @@ class _BayesBase(nn.Module):
             out.append((self.mu_bias, self.rho_bias, self.prior_mu_bias, self.prior_rho_bias))
         return out
 
+    def _sigma(self):
+        rho = self.rho_weight
+        return self._cache.get("sigma", [rho], lambda: ops.bnn_sample(torch.zeros_like(rho), rho.detach(), 1, torch.ones_like(rho))[0])
+
     def _sampled(self, B, packed_mk=None):
         """(weights (nsets,*shape), bias (nsets,C)|None, nsets) for this forward; with ``packed_mk = (M, K)`` the sampled
         weights come back already packed for the x6 GEMM (stochastic mode only)."""
@@ -305,22 +311,27 @@ class _BayesBase(nn.Module):
         if ctx is None:      # leaf used outside a Network forward: one-off context (fresh epoch)
             ctx = SampleCtx(B, None, seed=torch.initial_seed() & 0xFFFFFFFF)
         ns = ctx.nsets
+        bank = ctx.bank
+        if bank is not None:                         # this forward's draws were all made by one launch (EvalSampleBank)
+            return bank.take(self, packed_mk, ns)
         ew = eb = None
         if ctx.eps is not None:
             ew = ctx.eps[self.module_path + ".weight"].contiguous()
             if self.bias:
                 eb = ctx.eps[self.module_path + ".bias"].contiguous()
+        rec = {"mk": packed_mk if (packed_mk is not None and ops.USE_X6) else None, "b": None}
         if packed_mk is not None and ops.USE_X6:
             # GEMM weights go straight into operand order (same Philox stream ids, same values as sample-then-pack)
             # sigma = log1p(exp(rho)) once per weight version (one launch of the sampler with mu = 0, eps = 1), not once per sample
-            rho = self.rho_weight
-            sigma = self._cache.get("sigma", [rho], lambda: ops.bnn_sample(torch.zeros_like(rho), rho.detach(), 1, torch.ones_like(rho))[0])
-            w = ops.bnn_sample_packed(self.mu_weight.detach(), sigma, ns, packed_mk[0], packed_mk[1], ew, ctx.seed, ctx.next_stream(), sigma_given=True, stream_add=ctx.epoch_dev)
+            w = ops.bnn_sample_packed(self.mu_weight.detach(), self._sigma(), ns, packed_mk[0], packed_mk[1], ew, ctx.seed, ctx.next_stream(), sigma_given=True, stream_add=ctx.epoch_dev)
         else:
             w = ops.bnn_sample(self.mu_weight.detach(), self.rho_weight.detach(), ns, ew, ctx.seed, ctx.next_stream(), ctx.epoch_dev)
+        rec["w"] = ctx.counter - ctx.counter0
         b = None
         if self.bias:
             b = ops.bnn_sample(self.mu_bias.detach(), self.rho_bias.detach(), ns, eb, ctx.seed, ctx.next_stream(), ctx.epoch_dev)
+            rec["b"] = ctx.counter - ctx.counter0
+        self.__dict__["_eval_draw"] = rec            # which streams of the forward this leaf drew from, and in which form (EvalSampleBank)
         return w, b, ns
 
 
@@ -420,6 +431,91 @@ class BayesBank:
             else:
                 m._bs, m._eps_b = wv, ev
         step.bank = self
+
+
+class EvalSampleBank:
+    """The N weight sets of every Bayesian tensor of a net, for one stochastic (eval) forward, drawn by ONE launch (bem_bnn_ebank_sample_f32)
+    into a flat arena; the leaves then take views of it.  Leaf by leaf the Stage-I net of the Monte-Carlo loop issues 90 sampling launches
+    per forward between its layers' kernels, on planes of H/16 x W/16 pixels where every dependent launch costs >= 5 us.
+
+    Built after a leaf-by-leaf Philox forward, which records for every leaf the form it asked for (x6-packed GEMM operand or natural
+    order) and the streams it drew from: the bank gives each tensor that same stream, so its values are the per-leaf path's values.
+    Rebuilt when the number of sets, a parameter, a cached sigma or a leaf's form changes.  Injected eps take the per-leaf path."""
+
+    def __init__(self, net):
+        self.leaves = [m for m in net.modules() if isinstance(m, _BayesBase)]
+        self.sig = None
+
+    def usable(self, ctx):
+        return (ctx is not None and ctx.eps is None and ctx.epoch_dev is None and bool(self.leaves) and ops.USE_X6
+                and all(not m.training and not m.deterministic and "_eval_draw" in m.__dict__ for m in self.leaves))
+
+    def _signature(self, ns):
+        sig = [ns]
+        for m in self.leaves:
+            d = m._eval_draw
+            sig += [d["mk"], d["w"], d["b"], m.mu_weight.data_ptr(), (m._sigma() if d["mk"] else m.rho_weight).data_ptr()]
+            if m.bias:
+                sig += [m.mu_bias.data_ptr(), m.rho_bias.data_ptr()]
+        return tuple(sig)
+
+    def _build(self, ns):
+        dev = self.leaves[0].mu_weight.device
+        rows, blks, off, self.views = [], [], 0, {}
+        order = []
+        for m in self.leaves:
+            d = m._eval_draw
+            if d["mk"] is not None:
+                M, K = d["mk"]
+                pe = ops.packed_elems(M, K, True)
+                items = ns * ((M + 31) // 32) * ((K + 15) // 16) * 64
+                rows.append([m.mu_weight.data_ptr(), m._sigma().data_ptr(), off, M * K, M | (K << 32), d["w"], items, ns * M * K])
+                wv = (off, ns * pe, (ns, pe), (M, K))
+                off += ns * pe
+            else:
+                n = m.mu_weight.numel()
+                rows.append([m.mu_weight.data_ptr(), m.rho_weight.data_ptr(), off, n, 0, d["w"], (ns * n + 3) // 4, ns * n])
+                wv = (off, ns * n, (ns,) + tuple(m.mu_weight.shape), None)
+                off += (ns * n + 3) // 4 * 4
+            bv = None
+            if m.bias:
+                n = m.mu_bias.numel()
+                rows.append([m.mu_bias.data_ptr(), m.rho_bias.data_ptr(), off, n, 0, d["b"], (ns * n + 3) // 4, ns * n])
+                bv = (off, ns * n, (ns,) + tuple(m.mu_bias.shape), None)
+                off += (ns * n + 3) // 4 * 4
+            order.append((m, wv, bv))
+        for s_, r in enumerate(rows):
+            blks += [[s_, b] for b in range((r[6] + 255) // 256)]
+        if sorted(r[5] for r in rows) != list(range(1, len(rows) + 1)):
+            return False                                 # the recorded forward did not draw every Bayesian tensor exactly once: stay leaf by leaf
+        self.arena = torch.empty(off, device=dev, dtype=torch.float32)
+        for m, wv, bv in order:
+            w = self.arena[wv[0]:wv[0] + wv[1]].view(wv[2])
+            if wv[3] is not None:
+                w._bem_mk = wv[3]
+            b = None if bv is None else self.arena[bv[0]:bv[0] + bv[1]].view(bv[2])
+            self.views[id(m)] = (m._eval_draw["mk"], w, b)
+        self.nblk, self.nrows = len(blks), len(rows)
+        self.segs = torch.tensor(rows, dtype=torch.int64).to(dev)
+        self.blks = torch.tensor(blks, dtype=torch.int32).to(dev)
+        self.sig = self._signature(ns)
+        return True
+
+    def sample(self, ctx):
+        ns = ctx.nsets
+        if self.sig != self._signature(ns) and not self._build(ns):
+            self.sig = None
+            return
+        base = (ctx.rank << 44) | (ctx.epoch << 20) | ctx.counter
+        ops.bnn_ebank_sample(self, ctx.seed, base)
+        ctx.counter += self.nrows
+        ctx.bank = self
+
+    def take(self, leaf, packed_mk, ns):
+        mk, w, b = self.views[id(leaf)]
+        if mk != (packed_mk if (packed_mk is not None and ops.USE_X6) else None):
+            raise BemNativeError("EvalSampleBank: a leaf asked for its weights in another form than in the recorded forward")
+        return w, b, ns
 
 
 class Conv2dReparameterization(_BayesBase):

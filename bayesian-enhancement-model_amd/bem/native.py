@@ -68,6 +68,7 @@ SIGNATURES = {
     "bem_pw_x6_packed_elems": [I, I],
     "bem_bnn_sample_pack_x6": [P, P, P, P, I, I, I, U64, U64, P, I, P],
     "bem_store_words": [P, P, I, P],
+    "bem_bnn_ebank_sample_f32": [P, P, I, P, U64, U64, P],
     "bem_bnn_bank_sample_f32": [P, P, I, P, P, P, P, P, F, P, U64, U64, P, P],
     "bem_bnn_bank_kl_f32": [P, P, I, P, P, P, P],
     "bem_bnn_bank_kl_bwd_f32": [P, P, I, P, P, P, P],

@@ -654,6 +654,10 @@ def bnn_bank_sample(bank, decay, decay_dev, seed, stream_base, stream_add):
                                         float(decay), _p(decay_dev), seed, stream_base, _p(stream_add), _stream()), "bnn_bank_sample")
 
 
+def bnn_ebank_sample(bank, seed, stream_base):
+    check(lib().bem_bnn_ebank_sample_f32(_p(bank.segs), _p(bank.blks), bank.nblk, _p(bank.arena), seed, stream_base, _stream()), "bnn_ebank_sample")
+
+
 def bnn_bank_kl_(bank, out):
     _chk(out, "out")
     check(lib().bem_bnn_bank_kl_f32(_p(bank.segs), _p(bank.blks), bank.nblk, _p(bank.pm), _p(bank.pr), _p(out), _stream()), "bnn_bank_kl")

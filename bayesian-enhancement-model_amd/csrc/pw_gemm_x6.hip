@@ -546,12 +546,9 @@ __global__ void pack_x6_kernel(const float* __restrict__ W, u32x4* __restrict__ 
 // Bayesian weight sets straight into operand order: w[set][row][k] = mu + log1p(exp(rho)) * eps, eps injected or drawn
 // with the sampler's own Philox stream (element index i = set*M*K + row*K + k, as bem_bnn_sample_f32 numbers it), split
 // and stored like pack_x6_kernel does -- the natural-order copy (one write + one read per weight and sample) is skipped.
-__global__ void sample_pack_x6_kernel(const float* __restrict__ mu, const float* __restrict__ rho, const float* __restrict__ eps_in,
-                                      u32x4* __restrict__ Wp, int M, int K, int MT, int KB, int64_t total, uint64_t seed, uint64_t stream_id,
-                                      const uint64_t* __restrict__ stream_add, int sigma_given) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    if (stream_add) stream_id += stream_add[0];                          // device-resident part of the id (see randn_kernel)
+__device__ __forceinline__ void sample_pack_x6_item(int64_t i, const float* __restrict__ mu, const float* __restrict__ rho,
+                                                    const float* __restrict__ eps_in, u32x4* __restrict__ Wp, int M, int K, int MT, int KB,
+                                                    uint64_t seed, uint64_t stream_id, int sigma_given) {
     const int lane = (int)(i & 63);
     const int64_t blk = i >> 6;
     const int kb = (int)(blk % KB), mt = (int)((blk / KB) % MT);
@@ -585,7 +582,63 @@ __global__ void sample_pack_x6_kernel(const float* __restrict__ mu, const float*
     o[0] = h; o[64] = m; o[128] = l;
 }
 
+__global__ void sample_pack_x6_kernel(const float* __restrict__ mu, const float* __restrict__ rho, const float* __restrict__ eps_in,
+                                      u32x4* __restrict__ Wp, int M, int K, int MT, int KB, int64_t total, uint64_t seed, uint64_t stream_id,
+                                      const uint64_t* __restrict__ stream_add, int sigma_given) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    if (stream_add) stream_id += stream_add[0];                          // device-resident part of the id (see randn_kernel)
+    sample_pack_x6_item(i, mu, rho, eps_in, Wp, M, K, MT, KB, seed, stream_id, sigma_given);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// All Bayesian tensors of a net drawn for a stochastic (eval) forward in ONE launch: the Stage-I net of the Monte-Carlo loop has 60
+// Bayesian leaves / 90 tensors, i.e. 90 sampling launches per forward that sit between the layers' own kernels on planes of H/16 x W/16
+// pixels, where every dependent launch costs >= 5 us whatever it does.  Segments of a flat output arena:
+//   seg = { mu, sig (sigma = log1p(exp(rho)) precomputed for packed 1x1 weights, rho otherwise), first float of the tensor's nsets outputs
+//           in the arena, n = elements per set, M, K (packed x6 operand order for the GEMM kernels; K = 0: natural order, as
+//           bem_bnn_sample_f32 writes depthwise weights and biases), stream counter, work items, nsets * n }
+//   blk = { segment, first work item }: one workgroup = 256 work items of one segment (packed: sample_pack_x6_item; natural: 4 elements)
+// Values are those of bem_bnn_sample_pack_x6 (sigma_given) / bem_bnn_sample_f32 for (seed, stream_base + counter).
+// ------------------------------------------------------------------------------------------------------------------------
+struct ebank_seg { const float* mu; const float* sig; int64_t out; int64_t n; int32_t M, K; uint64_t counter; int64_t items; int64_t total; };
+static_assert(sizeof(ebank_seg) == 8 * 8, "ebank_seg is eight 64-bit words (bem.modules.EvalSampleBank builds it as an int64 table)");
+struct ebank_blk { int32_t seg; int32_t first; };
+
+__global__ __launch_bounds__(256) void ebank_sample_kernel(const ebank_seg* __restrict__ segs, const ebank_blk* __restrict__ blks,
+                                                           float* __restrict__ arena, uint64_t seed, uint64_t stream_base) {
+    const ebank_blk bk = blks[blockIdx.x];
+    const ebank_seg sg = segs[bk.seg];
+    const int64_t i = (int64_t)bk.first * 256 + threadIdx.x;
+    if (i >= sg.items) return;
+    const uint64_t sid = stream_base + sg.counter;
+    float* out = arena + sg.out;
+    if (sg.K > 0) {
+        sample_pack_x6_item(i, sg.mu, sg.sig, nullptr, reinterpret_cast<u32x4*>(out), sg.M, sg.K, (sg.M + 31) / 32, (sg.K + 15) / 16, seed, sid, 1);
+        return;
+    }
+    const int64_t i0 = 4 * i, total = sg.total;                                       // natural order: total = nsets * n elements
+    float z[4];
+    philox_normal4(i, seed, sid, z);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t e = i0 + q;
+        if (e < total) {
+            const int64_t k = e % sg.n;
+            out[e] = sg.mu[k] + log1pf(expf(sg.sig[k])) * z[q];
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int bem_bnn_ebank_sample_f32(const void* segs, const void* blks, int nblk, float* arena, uint64_t seed, uint64_t stream_base,
+                                        void* stream) {
+    BEM_REQUIRE(segs && blks && arena && nblk > 0, "bnn_ebank_sample: bad arguments");
+    BEM_REQUIRE(((uintptr_t)arena & 15) == 0, "bnn_ebank_sample: the arena must be 16-byte aligned");
+    ebank_sample_kernel<<<nblk, 256, 0, (hipStream_t)stream>>>((const ebank_seg*)segs, (const ebank_blk*)blks, arena, seed, stream_base);
+    return bem_check_launch("bnn_ebank_sample");
+}
 
 extern "C" int bem_bnn_sample_pack_x6(const float* mu, const float* rho, const float* eps_in, float* Wp, int nsets, int M, int K,
                                       uint64_t seed, uint64_t stream_id, const uint64_t* stream_add, int sigma_given, void* stream) {

@@ -246,6 +246,14 @@ int bem_space_to_depth_f32(const float* x, float* out, int B, int C, int H, int 
 /* nn.PixelShuffle(2): (B,4C,H,W) -> (B,C,2H,2W). */
 int bem_pixel_shuffle2_f32(const float* x, float* out, int B, int C, int H, int W, void* stream);
 
+/* Every Bayesian tensor of a net drawn for a stochastic forward in one launch (the N weight sets per leaf of eval.py:199-211, all leaves).
+ * segs: nseg x 8 64-bit words {mu, sig pointers (sig = precomputed sigma for packed tensors, rho for natural ones); first float of the
+ * tensor's output in `arena` (multiple of 4); n = elements per set; int32 M, int32 K (K > 0: the nsets sets in x6 operand order exactly as
+ * bem_bnn_sample_pack_x6 with sigma_given writes them; K = 0: natural order as bem_bnn_sample_f32); stream counter; work items (packed:
+ * nsets * ceil(M/32) * ceil(K/16) * 64, natural: ceil(nsets * n / 4)); nsets * n}; blks: nblk x {int32 segment, int32 first block of 256
+ * work items}.  Draws: (seed, stream_base + counter), element numbering of the per-tensor entry points. */
+int bem_bnn_ebank_sample_f32(const void* segs, const void* blks, int nblk, float* arena, uint64_t seed, uint64_t stream_base, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * DecompDualBranch's bottleneck blocks (basicsr/archs/DecompModel_arch.py:57-99).
  * ------------------------------------------------------------------------------------------- */

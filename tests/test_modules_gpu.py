@@ -514,6 +514,10 @@ def test_bench_step_reproducible_under_full_load():
         d = float((f - runs[0][0]).abs().max())
         assert d <= 2e-6, d
         assert float((p - runs[0][1]).abs().max()) <= 1e-4
+    # the first stochastic forward draws its weight sets leaf by leaf (90 launches) and records the streams; the later ones make all draws in
+    # one launch (EvalSampleBank) from those same streams -- the runs above therefore compare the two forms
+    bank = net1.__dict__.get("_eval_bank")
+    assert bank is not None and bank.sig is not None and bank.nrows == sum(2 if m.bias else 1 for m in bank.leaves) == 90
     assert torch.isfinite(runs[0][0]).all()
 
 
