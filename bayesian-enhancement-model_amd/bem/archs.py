@@ -230,8 +230,7 @@ class DecompDualBranchDDWavelet(nn.Module):
             if spi == 1:
                 ops.copy_channels(d_img, q, 0, src_c0=16 * bi, C=16)
             else:
-                for i in range(d_img.shape[0]):
-                    _bcast_copy(d_img, i, q, spi, 16 * bi)
+                ops.copy_channels_rep(d_img, q, 0, spi, src_c0=16 * bi, C=16)
             ops.copy_channels(d_cond, q, 16, src_c0=16 * bi, C=16)
             f = getattr(self, f"first_conv_{br}")(q)
             sk = []
@@ -268,16 +267,6 @@ class DecompDualBranchDDWavelet(nn.Module):
         with torch.enable_grad() if train else torch.no_grad():
             out = self.forward_decomposed(d_img, d_cond)
         return [x, out]
-
-
-def _bcast_copy(d_img, i, q, spi, src_c0):
-    """q[i*spi:(i+1)*spi, 0:16] = d_img[i, src_c0:src_c0+16] (batch stride 0 on the source)."""
-    import ctypes
-    from .native import check, lib
-    L = d_img.shape[2] * d_img.shape[3]
-    src = ctypes.c_void_p(d_img.data_ptr() + 4 * ((i * d_img.shape[1] + src_c0) * L))
-    dst = ctypes.c_void_p(q.data_ptr() + 4 * (i * spi * q.shape[1] * L))
-    check(lib().bem_copy_channels_f32(src, 0, dst, q.shape[1] * L, spi, 16, L, ops._stream()), "copy_channels(bcast)")
 
 
 # ------------------------------------------------------------------------------------------------

@@ -106,6 +106,7 @@ SIGNATURES = {
     "bem_attn_fold_f32": [P, P, P, P, P, P, I, I, P],
     "bem_transpose_planes_f32": [P, I64, P, I64, I, I, I, I, P],
     "bem_copy_channels_f32": [P, I64, P, I64, I, I, I, P],
+    "bem_copy_channels_rep_f32": [P, I64, P, I64, I, I, I, I, P],
     "bem_add_channels_f32": [P, I64, P, I64, I, I, I, P],
     "bem_bilinear_up_f32": [P, I64, P, I64, I, I, I, I, I, P],
     "bem_space_to_depth_f32": [P, P, I, I, I, I, P],

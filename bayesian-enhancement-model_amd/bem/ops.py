@@ -583,6 +583,20 @@ def copy_channels(src, dst, dst_c0, src_c0=0, C=None):
     return dst
 
 
+def copy_channels_rep(src, dst, dst_c0, rep, src_c0=0, C=None):
+    """dst[b, dst_c0:dst_c0+C] = src[b // rep, src_c0:src_c0+C]  (dst has rep times the rows of src)."""
+    _chk(src, "src"); _chk(dst, "dst")
+    Bs, Cs = src.shape[0], src.shape[1]
+    C = Cs - src_c0 if C is None else C
+    L = src[0, 0].numel()
+    if dst.shape[0] != Bs * rep or dst[0, 0].numel() != L or dst_c0 + C > dst.shape[1] or src_c0 + C > Cs:
+        raise ValueError("copy_channels_rep: shapes")
+    check(lib().bem_copy_channels_rep_f32(ctypes.c_void_p(src.data_ptr() + 4 * src_c0 * L), Cs * L,
+                                          ctypes.c_void_p(dst.data_ptr() + 4 * dst_c0 * L), dst.shape[1] * L, Bs * rep, C, L, int(rep),
+                                          _stream()), "copy_channels_rep")
+    return dst
+
+
 def add_channels(src, dst, dst_c0, src_c0=0, C=None):
     """dst[:, dst_c0:dst_c0+C] += src[:, src_c0:src_c0+C] (same spatial size)."""
     _chk(src, "src"); _chk(dst, "dst")

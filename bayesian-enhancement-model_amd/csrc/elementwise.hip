@@ -161,7 +161,8 @@ constexpr int ATT_C = 32;
 constexpr int ATT_CHUNK = 2048;
 __global__ __launch_bounds__(256) void attn_stats_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                          double* __restrict__ stats, int L) {
-    __shared__ float t1[ATT_C][65], t2[ATT_C][65];
+    __shared__ double t1[ATT_C][65], t2[ATT_C][65];     // converted once when the tile is staged: the product loop is then f64 FMAs only (it was
+                                                        // 4 v_cvt_f64_f32 per 4 FMAs: the conversions, not the arithmetic, set the kernel's time)
     const int b = blockIdx.y;
     const int p0 = blockIdx.x * ATT_CHUNK;
     const int i0 = (threadIdx.x >> 4) * 2, j0 = (threadIdx.x & 15) * 2;
@@ -174,8 +175,8 @@ __global__ __launch_bounds__(256) void attn_stats_kernel(const float* __restrict
         for (int i = threadIdx.x; i < ATT_C * 64; i += 256) {
             const int c = i >> 6, pp = i & 63;
             const int p = ps + pp;
-            t1[c][pp] = p < pend ? F1[(int64_t)c * L + p] : 0.f;
-            t2[c][pp] = p < pend ? F2[(int64_t)c * L + p] : 0.f;
+            t1[c][pp] = p < pend ? (double)F1[(int64_t)c * L + p] : 0.0;
+            t2[c][pp] = p < pend ? (double)F2[(int64_t)c * L + p] : 0.0;
         }
         __syncthreads();
 #pragma unroll 8
@@ -338,6 +339,15 @@ __global__ void copy_channels_kernel(const float* __restrict__ src, int64_t src_
     dst[b * dst_bs + r] = src[b * src_bs + r];
 }
 
+// dst row b takes the channels of src row b / rep: an image's planes handed to its `rep` Monte-Carlo samples in one launch
+__global__ void copy_channels_rep_kernel(const float* __restrict__ src, int64_t src_bs, float* __restrict__ dst,
+                                         int64_t dst_bs, int64_t CL, int64_t total, int rep) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t b = i / CL, r = i - b * CL;
+    dst[b * dst_bs + r] = src[(b / rep) * src_bs + r];
+}
+
 __global__ void add_channels_kernel(const float* __restrict__ src, int64_t src_bs, float* __restrict__ dst,
                                     int64_t dst_bs, int64_t CL, int64_t total) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -468,7 +478,17 @@ __global__ __launch_bounds__(256) void plane_mean_kernel(const float* __restrict
     __shared__ double sh[4];
     const float* p = x + (int64_t)blockIdx.x * Hs * Ws;
     double s = 0;
-    for (int i = threadIdx.x; i < h * w; i += 256) s += (double)p[(int64_t)(i / w) * Ws + (i % w)];
+    if (w == Ws && (w & 3) == 0 && (((uintptr_t)p) & 15) == 0) {          // whole rows of an aligned plane: 16-byte loads, no index arithmetic
+        const float4* p4 = reinterpret_cast<const float4*>(p);
+        double s1 = 0, s2 = 0, s3 = 0;
+        for (int i = threadIdx.x; i < h * w / 4; i += 256) {
+            const float4 v = p4[i];
+            s += (double)v.x; s1 += (double)v.y; s2 += (double)v.z; s3 += (double)v.w;
+        }
+        s += s1 + s2 + s3;
+    } else {
+        for (int i = threadIdx.x; i < h * w; i += 256) s += (double)p[(int64_t)(i / w) * Ws + (i % w)];
+    }
     s = block_sum(s, sh);
     if (threadIdx.x == 0) means[blockIdx.x] = (float)(s / ((double)h * w));
 }
@@ -809,6 +829,16 @@ extern "C" int bem_copy_channels_f32(const float* src, int64_t src_bstride, floa
     if (total == 0) return BEM_OK;
     copy_channels_kernel<<<GRID1D(total), 256, 0, (hipStream_t)stream>>>(src, src_bstride, dst, dst_bstride, (int64_t)C * L, total);
     return bem_check_launch("copy_channels");
+}
+
+extern "C" int bem_copy_channels_rep_f32(const float* src, int64_t src_bstride, float* dst, int64_t dst_bstride, int B, int C, int L, int rep,
+                                         void* stream) {
+    BEM_REQUIRE(src && dst, "copy_channels_rep: null tensor");
+    BEM_REQUIRE(B >= 0 && C > 0 && L >= 0 && rep >= 1, "copy_channels_rep: bad shape");
+    const int64_t total = (int64_t)B * C * L;
+    if (total == 0) return BEM_OK;
+    copy_channels_rep_kernel<<<GRID1D(total), 256, 0, (hipStream_t)stream>>>(src, src_bstride, dst, dst_bstride, (int64_t)C * L, total, rep);
+    return bem_check_launch("copy_channels_rep");
 }
 
 extern "C" int bem_add_channels_f32(const float* src, int64_t src_bstride, float* dst, int64_t dst_bstride, int B,

@@ -235,6 +235,10 @@ int bem_transpose_planes_f32(const float* src, int64_t src_bstride, float* dst, 
 /* dst[b][dst_c0 + c][l] = src[b][c][l]  (c < C), strides in elements. */
 int bem_copy_channels_f32(const float* src, int64_t src_bstride, float* dst, int64_t dst_bstride,
                           int B, int C, int L, void* stream);
+/* The same with dst row b reading src row b / rep (B = dst rows): decomp(image), evaluated once per image, handed to its rep
+ * Monte-Carlo samples (the loop of eval.py:199-213 feeds the same image to every sample). */
+int bem_copy_channels_rep_f32(const float* src, int64_t src_bstride, float* dst, int64_t dst_bstride, int B, int C, int L, int rep,
+                              void* stream);
 /* dst[b][c][l] += src[b][c][l]  (c < C); DecompDualBranch2's "Q + [cond, 0]" (DecompDualBranch_arch.py:241-246). */
 int bem_add_channels_f32(const float* src, int64_t src_bstride, float* dst, int64_t dst_bstride,
                          int B, int C, int L, void* stream);

@@ -335,6 +335,8 @@ def test_mc_postproc_and_finalize(ops):
     P = torch.randn(2 * N, 3, Hp, Wp, generator=g) * 0.4 + 0.5
     T = torch.rand(2, 3, hh, ww, generator=g)
     close(ops.plane_mean(dev(P), hh, ww), P[:, :, :hh, :ww].mean(dim=(2, 3)), 1e-5, 1e-6, "plane mean")
+    close(ops.plane_mean(dev(P)), P.mean(dim=(2, 3)), 1e-5, 1e-6, "plane mean, whole aligned planes (16-byte loads)")
+    close(ops.plane_mean(dev(P[:, :, :, :21].contiguous())), P[:, :, :, :21].mean(dim=(2, 3)), 1e-5, 1e-6, "plane mean, whole planes of odd width")
     fin, ps = ops.candidate_finalize(dev(P), dev(T), N, hh, ww, True)
     for i in range(2 * N):
         q = P[i, :, :hh, :ww].clamp(0, 1).permute(1, 2, 0).numpy()
