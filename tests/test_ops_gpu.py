@@ -1,5 +1,6 @@
 """GPU parity: every HIP kernel (through the C ABI / bem.ops) against the CPU oracle on the same
 seeded inputs, plus the reference-generated golden vectors.  Tolerances are stated per test."""
+import ctypes
 import numpy as np
 import pytest
 import torch
@@ -656,6 +657,21 @@ def test_selective_scan_cuda_oflex_16bit_inputs(dtype, L):
     want = v.to(dtype)
     assert torch.equal(torch.isnan(low), torch.isnan(want)) and torch.equal(low[~torch.isnan(low)], want[~torch.isnan(want)])
     assert torch.equal(ext._f32(want[~torch.isnan(want)]), want[~torch.isnan(want)].float())
+
+
+@pytest.mark.parametrize("H,W", [(64, 64), (37, 29), (128, 128), (5, 3)])
+def test_attn_stats_f64(H, W):
+    """bem_attn_stats_f64 (the Gram matrix and channel sums the folded cross attention of QD/model4.py:99-139 is built from): f64 sums of
+    f32 inputs against torch.float64, over chunk boundaries (2048 pixels), ragged tails and unaligned row lengths."""
+    from bem import native
+    g = torch.Generator().manual_seed(H * 131 + W)
+    f1, f2 = dev(torch.randn(3, 32, H, W, generator=g)), dev(torch.randn(3, 32, H, W, generator=g) * 0.5 + 0.1)
+    stats = torch.empty(3, 32 * 32 + 64, device=f1.device, dtype=torch.float64)
+    native.check(native.lib().bem_attn_stats_f64(ctypes.c_void_p(f1.data_ptr()), ctypes.c_void_p(f2.data_ptr()), ctypes.c_void_p(stats.data_ptr()), 3, H * W,
+                                                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "attn_stats")
+    a, b = f1.double().reshape(3, 32, -1).cpu(), f2.double().reshape(3, 32, -1).cpu()
+    want = torch.cat([torch.einsum("bip,bjp->bij", a, b).reshape(3, -1), a.sum(-1), b.sum(-1)], 1)
+    assert torch.allclose(stats.cpu(), want, rtol=1e-12, atol=1e-10), float((stats.cpu() - want).abs().max())
 
 
 def test_hamilton_product_reference_name():
