@@ -68,20 +68,27 @@ def spawn_ranks(args):
     sys.exit(r.returncode)
 
 
-def committed_traffic(kernel_symbol):
+def committed_traffic(kernel_symbol, train=False, prefixes=None):
     """HBM bytes per launch of the roofline kernel from the committed counter passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-    runs cannot be collected inside a timed run): profiles/r03_traffic.json, written by profiles/make_traffic.py."""
-    path = os.path.join(ROOT, "profiles", "r03_traffic.json")
+    runs cannot be collected inside a timed run): profiles/r03_traffic.json (eval step) / r03_traffic_train.json (Stage-II training step),
+    written by profiles/make_traffic.py.  ``prefixes``: kernel-name prefixes that together make up one profiled op launch (the first one
+    is the op's main kernel: the bytes of all matching rows are divided by ITS launch count)."""
+    name = "r03_traffic_train.json" if train else "r03_traffic.json"
+    path = os.path.join(ROOT, "profiles", name)
+    prefixes = prefixes or [kernel_symbol.split("(")[0].strip()]
     try:
         with open(path) as f:
             t = json.load(f)
-        for row in t.get("kernels", []):
-            if row["kernel"].startswith(kernel_symbol.split("(")[0]):
-                return {"traffic": row["bytes_per_launch"], "traffic_source": {"file": "profiles/r03_traffic.json", "commit": t.get("commit"),
-                                                                              "launches": row.get("launches"), "fetch_factor": row.get("fetch_factor")}}
+        rows = [r for r in t.get("kernels", []) if any(r["kernel"].startswith(p) for p in prefixes)]
+        main = [r for r in rows if r["kernel"].startswith(prefixes[0])]
+        if main:
+            n = sum(r["launches"] for r in main)
+            return {"traffic": sum(r["bytes_per_launch"] * r["launches"] for r in rows) / n,
+                    "traffic_source": {"file": "profiles/" + name, "commit": t.get("commit"), "launches": n, "kernels": sorted({r["kernel"] for r in rows}),
+                                       "fetch_factor": main[0].get("fetch_factor")}}
     except (OSError, ValueError, KeyError):
         pass
-    return {"traffic": None, "traffic_source": "profiles/r03_traffic.json has no row for this kernel (counter passes are separate rocprofv3 runs)"}
+    return {"traffic": None, "traffic_source": f"profiles/{name} has no row for this kernel (counter passes are separate rocprofv3 runs)"}
 
 
 def cpu_model():
@@ -326,7 +333,12 @@ def main():
             avg_ms = prof["ms"] / prof["launches"]
             rl = {"kernel": prof["kernel"], "bound": prof["bound"], "launches": prof["launches"], "avg_launch_us": avg_ms * 1e3,
                   "algorithmic_bytes_per_launch": prof["bytes"] / prof["launches"]}
-            rl.update(committed_traffic(prof["kernel"]))
+            if train and not stage1:
+                rl.update(committed_traffic(prof["kernel"], True, ["wgrad_x6_kernel", "wgrad_x6_reduce_kernel"]))
+            elif not train:
+                rl.update(committed_traffic(prof["kernel"]))
+            else:
+                rl.update(traffic=None, traffic_source="no counter pass of the Stage-I training step is kept (launch-bound: see config.note)")
             if prof["bound"].startswith("mfma"):
                 peak = MFMA_BF16_PEAK_TFLOPS if prof["bound"] == "mfma_bf16" else MFMA_F32_PEAK_TFLOPS
                 ach = prof["flops"] / prof["launches"] / (avg_ms * 1e-3) / 1e12
@@ -346,6 +358,7 @@ def main():
                                         "avg_launch_us": avg2 * 1e3, "algorithmic_bytes_per_launch": prof2["bytes"] / prof2["launches"],
                                         "achieved": ach2, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach2 / HBM_PEAK_GBS,
                                         "note": "HIP events over two extra steps after the timed region"}
+            out["roofline_scan_bwd"].update(committed_traffic("ss2d_scan_bwd_rows_kernel", True))
         # whole-path fraction of the HBM roofline on SURVEY 8d's algorithmic bytes of what the code does (decomp(image) hoisted out of the
         # sample loop in eval); the un-hoisted figure is printed next to it
         out["path_hbm_roofline_frac"] = (out["value"] / world) * (bytes_img - hoist) / (HBM_PEAK_GBS * 1e9)
