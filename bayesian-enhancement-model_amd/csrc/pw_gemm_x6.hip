@@ -397,6 +397,107 @@ __global__ __launch_bounds__(256, 2) void pw_x6_res_kernel(PwX k) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// resident, weights through LDS: K = 16 * KBM exactly, many M-tiles (level-2 project_in: K 160 -> M 1280).  In pw_x6_res_kernel each
+// of the four waves pulls every weight block from L2 for its own 32 pixels, one k-block ahead: 1.2 MB per wave at two waves per SIMD is a
+// latency chain (7 TB/s of L2 reads in flight-limited pieces, matrix pipe 15 % busy).  Here the workgroup fetches an M-tile's KBM * 3 KiB of
+// weights ONCE by LDS-DMA, a whole M-tile ahead of the MFMAs that read it, and the four waves share it: a quarter of the L2 traffic and
+// 30 KiB in flight per workgroup.  One barrier per M-tile; waves beyond the image keep running (masked stores) so that every wave reaches it.
+// ------------------------------------------------------------------------------------------------
+template <int KBM, bool SUM, bool VEC>
+__global__ __launch_bounds__(256, 2) void pw_x6_res_lds_kernel(PwX k) {
+    __shared__ float s_ln[2 * 16 * KBM];
+    __shared__ __attribute__((aligned(16))) float s_bias[BEM_X6_MAXM];
+    __shared__ __attribute__((aligned(16))) u32x4 Ws[2][KBM * 3 * 64];
+    stage_bias(k, blockIdx.z, s_bias);
+    for (int i = threadIdx.x; i < 16 * KBM; i += 256) {
+        const bool on = k.ln_w && i < k.K;
+        s_ln[i] = on ? k.ln_w[min(i, k.K - 1)] : 0.f;
+        s_ln[16 * KBM + i] = on ? k.ln_b[min(i, k.K - 1)] : 0.f;
+    }
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), kh = lane >> 5, n = lane & 31;
+    const int b = blockIdx.z;
+    const int p0 = (xcd_tile(blockIdx.x, gridDim.x) * 4 + wave) * 32;
+    const int p = p0 + n;
+    bool keep[1] = {p < k.L};
+    const int pc = VEC ? (keep[0] ? p : 0) : p;
+    const int mt_lo = blockIdx.y * k.mtpb, mt_hi = min(k.MT, mt_lo + k.mtpb);
+    const u32x4* wsrc = k.Wp + (int64_t)b * k.w_bstride;
+    const int64_t mt_stride = (int64_t)KBM * 3 * 64;
+    auto dma = [&](int mt, int buf) {                               // KBM * 3 pieces of 1 KiB, dealt round-robin to the four waves
+        const u32x4* src = wsrc + (int64_t)mt * mt_stride;
+        for (int piece = wave; piece < KBM * 3; piece += 4)
+            glds16(src + piece * 64, (uint32_t)lane * 16u, lds_addr(&Ws[buf][piece * 64]));
+    };
+    dma(mt_lo, 0);
+    float xr[KBM][8][1];
+#pragma unroll
+    for (int kb = 0; kb < KBM; ++kb)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ldx<1, SUM, VEC>(k, b, 16 * kb + 8 * kh + e, pc, keep, xr[kb][e]);
+    __syncthreads();                                                // s_ln, s_bias visible
+    if (k.ln_w) {
+        const float inv = 1.f / (float)k.K;
+        float s = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < KBM; ++kb)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += xr[kb][e][0];
+        s += __shfl_xor(s, 32, 64);
+        const float mean = s * inv;
+        float q = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < KBM; ++kb)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = xr[kb][e][0] - mean;
+                q = fmaf(d, d, q);
+            }
+        q += __shfl_xor(q, 32, 64);
+        const float rstd = 1.f / sqrtf(q * inv + k.ln_eps);
+#pragma unroll
+        for (int kb = 0; kb < KBM; ++kb)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float g = valu_copy(s_ln[16 * kb + 8 * kh + e]), be = valu_copy(s_ln[16 * KBM + 16 * kb + 8 * kh + e]);
+                xr[kb][e][0] = (xr[kb][e][0] - mean) * rstd * g + be;
+            }
+    }
+    u32x4 xl[KBM][3];
+#pragma unroll
+    for (int kb = 0; kb < KBM; ++kb) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = xr[kb][e][0];
+        split8(v, xl[kb][0], xl[kb][1], xl[kb][2]);
+    }
+    int buf = 0;
+    for (int mt0 = mt_lo; mt0 < mt_hi; ++mt0, buf ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's pieces of M-tile mt0 have landed ...
+        __syncthreads();                                            // ... everybody's have, and everybody is done reading the other buffer
+        if (mt0 + 1 < mt_hi) dma(mt0 + 1, buf ^ 1);
+        f32x16 acc[1][1], alo;
+        float4 bq[1][4];
+        x6_load_bias<1>(k, b, mt0, kh, bq);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] = alo[r] = 0.f;
+        const u32x4* wl = &Ws[buf][lane];
+        u32x4 wn[3] = {wl[0], wl[64], wl[128]};
+#pragma unroll
+        for (int kb = 0; kb < KBM; ++kb) {                         // LDS reads one k-block ahead of the MFMAs, no further (register budget)
+            const u32x4 wc[3] = {wn[0], wn[1], wn[2]};
+            if (kb + 1 < KBM) {
+                wn[0] = wl[((kb + 1) * 3 + 0) * 64]; wn[1] = wl[((kb + 1) * 3 + 1) * 64]; wn[2] = wl[((kb + 1) * 3 + 2) * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mac6(wc, xl[kb], acc[0][0], alo);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        acc[0][0] += alo;
+        x6_epilogue<1, 1, VEC>(k, b, mt0, p, keep, kh, s_bias, bq, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // stream: any K, no LayerNorm.  grid (ceil(L / 256), ceil(MT / MTW), B); x one k-block ahead of the MFMAs.
 // ------------------------------------------------------------------------------------------------
 constexpr int BEM_X6_MAXK_LN = 1024;      // LayerNorm parameters of the streaming form live in LDS
@@ -721,6 +822,17 @@ extern "C" int bem_pw_gemm_x6_f32(const bem_pw_args* a, void* stream) {
     if (k.KB <= 3) BEM_X6_RES(3, 2, 1);
     if (ln && k.KB <= 5) BEM_X6_RES(5, 2, 1);
     static const bool res10 = !(getenv("BEM_X6_RES10") && atoi(getenv("BEM_X6_RES10")) == 0);       // A/B: the two-sweep streaming form instead
+    static const bool reslds = !(getenv("BEM_X6_RES_LDS") && atoi(getenv("BEM_X6_RES_LDS")) == 0);   // A/B: every wave streams its own weights from L2
+    if (ln && k.KB == 10 && k.K == 160 && k.MT >= 8 && res10 && reslds && (int64_t)a->B * cdiv(a->L, 32) >= 2048) {
+        // many M-tiles over a full-width K and enough pixels that a workgroup walks all of them: an M-tile's weights go through LDS once per
+        // workgroup (pw_x6_res_lds_kernel; level-2 project_in 335 -> 188 us).  With few pixels (Stage I) M is sliced over grid.y and the
+        // per-wave streaming form below is the faster one (50 vs 63 us).
+        dim3 grid(cdiv(a->L, 128), 1, a->B);
+        k.mtpb = k.MT;
+        if (!sum) pw_x6_res_lds_kernel<10, false, false><<<grid, 256, 0, s>>>(k);       // 32 pixels per wave: the scalar-pixel forms, as in BEM_X6_RES(10, 1, *)
+        else pw_x6_res_lds_kernel<10, true, false><<<grid, 256, 0, s>>>(k);
+        return bem_check_launch("pw_x6_res_lds");
+    }
     if (ln && k.KB <= 10 && res10) { if (k.MT == 1) BEM_X6_RES(10, 1, 1); else BEM_X6_RES(10, 1, 2); }
 #undef BEM_X6_RES
     {

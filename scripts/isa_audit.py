@@ -38,6 +38,7 @@ ALLOW_SCRATCH = {
     r"conv2d_mfma_kernel<4, 4, 2": "f32-MFMA im2col 4x4 stride-2: only for shapes the coalesced-row x6 kernel (conv4_x6.hip) does not take (output widths that are not a power of two <= 64, e.g. config 5) or BEM_CONV4_FAST=0",
     r"attn_fold_kernel": "one 1024-thread workgroup per image folding 8 32x32 matrices: 8 B, ~40 us per step",
     r"sample_pack_x6_kernel": "Stage-I weight sampling (Philox + Box-Muller + limb split per element, transcendental-bound): 48 B, 0.4 % of the step",
+    r"pw_x6_res_lds_kernel<10": "K = 160 resident with the M-tiles' weights shared through LDS (level-2 project_in): 8-12 B parked across the LayerNorm statistics of the prologue, none in the M-tile loop",
     r"pw_x6_res_kernel<10, 1, 2": "K <= 160 with LayerNorm and all K resident (level-2 blocks, 32x32 planes): 92 B; 0.5 % of the step",
     r"pw_x6_res_kernel<(5|10), (1|2), 1, (true|false), (true|false)>": "8 B in three rarely dispatched variants (odd L / sum input at level 1-2)",
     r"pw_x6_stream_kernel<3, 1,": "three M-tiles x one pixel sub-tile: measured variant kept for A/B, not dispatched by default",

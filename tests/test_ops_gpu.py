@@ -175,6 +175,32 @@ def test_pw_gemm_layernorm(ops, cfg):
     close(y, ref, 1e-4, 3e-5, f"ln pw {cfg}")
 
 
+@pytest.mark.parametrize("cfg", [(64, 320, 32, 32, False), (66, 288, 25, 40, False), (3, 1280, 32, 32, False), (2, 512, 7, 9, True), (64, 256, 4, 4, True),
+                                 (66, 288, 25, 40, True)])
+def test_pw_gemm_layernorm_k160_weights_through_lds(ops, cfg):
+    """K = 160 with LayerNorm and >= 8 M-tiles (level-2 project_in, 160 -> 1280): pw_x6_res_lds_kernel -- an M-tile's weights fetched once
+    per workgroup by LDS-DMA and shared by its four waves, one barrier per M-tile -- taken when B * L / 32 >= 2048 waves; below that the
+    per-wave streaming form with M sliced over grid.y.  Waves past the end of a ragged plane that must keep reaching the barriers, odd plane
+    sizes, bias + residual, the sum input, per-sample weights in both forms."""
+    B, M, H, W, per_sample = cfg
+    K = 160
+    g = torch.Generator().manual_seed(M + H)
+    x1, x2 = torch.randn(B, K, H, W, generator=g) * 2 + 0.5, torch.randn(B, K, H, W, generator=g)
+    lw, lb = torch.randn(K, generator=g), torch.randn(K, generator=g)
+    bias, res = torch.randn(M, generator=g), torch.randn(B, M, H, W, generator=g)
+    if per_sample:
+        w = torch.randn(B, M, K, generator=g) * K ** -0.5
+        n = O.layernorm2d_ref(x1, lw, lb)
+        ref = torch.stack([F.conv2d(n[i:i + 1], w[i][:, :, None, None])[0] for i in range(B)])
+        close(ops.pw_gemm(dev(x1), ops.pack_pw_weight(dev(w)), M, ln=(dev(lw), dev(lb))), ref, 1e-4, 3e-5, f"per-sample weights {cfg}")
+        return
+    w = torch.randn(M, K, generator=g) * K ** -0.5
+    ref = F.conv2d(O.layernorm2d_ref(x1, lw, lb), w[:, :, None, None], bias) + res
+    close(ops.pw_gemm(dev(x1), ops.pack_pw_weight(dev(w)), M, ln=(dev(lw), dev(lb)), bias=dev(bias), res=dev(res)), ref, 1e-4, 3e-5, f"ln + bias + res {cfg}")
+    ref = F.conv2d(O.layernorm2d_ref(x1 + x2, lw, lb), w[:, :, None, None])
+    close(ops.pw_gemm(dev(x1), ops.pack_pw_weight(dev(w)), M, x2=dev(x2), in_mode=1, ln=(dev(lw), dev(lb))), ref, 1e-4, 3e-5, f"sum + ln {cfg}")
+
+
 def test_pw_gemm_sum_cat_prelu_perbatch(ops):
     g = torch.Generator().manual_seed(5)
     B, C, M, H, W = 3, 24, 40, 6, 10
