@@ -402,10 +402,40 @@ class BayesBank:
             setattr(m, f"prior_rho_{kind}", pr[o:o + n].view(mu.shape))
             wv = self.w[o:o + n].view(mu.shape)
             wv.grad = self.gw[o:o + n].view(mu.shape)
+            if kind == "weight":
+                m.__dict__["_bank_wv"] = wv
             self.views.append((m, kind, wv, self.eps[o:o + n].view((1,) + tuple(mu.shape))))
         self.pm, self.pr = pm, pr
         self.segs = torch.tensor(rows, dtype=torch.int64).to(dev)
         self.blks = torch.tensor(blks, dtype=torch.int32).to(dev)
+        # the x6 operand forms of every 1x1 weight sample -- forward (M, K) and transposed (K, M, for the input-gradient GEMM) -- by ONE more
+        # launch (bem_pack_pw_weight_x6_jobs) instead of two small packing launches per layer and iteration
+        jobs, jblk, poff, self.packs = [], [], 0, []
+        if ops.USE_X6:
+            for (m, kind, mu, rho), r in zip(items, rows):
+                if kind != "weight" or not (getattr(m, "_is_pw", False) or isinstance(m, Linear2dReparameterization)):
+                    continue
+                M, K = mu.shape[0], mu.shape[1]
+                src = self.w.data_ptr() + 4 * r[4]
+                ent = []
+                for (Mj, Kj, rs, cs) in ((M, K, K, 1), (K, M, 1, K)):
+                    it = ((Mj + 31) // 32) * ((Kj + 15) // 16) * 64
+                    jobs.append([src, poff, Mj | (Kj << 32), rs, cs, it, 0, 0])
+                    jblk += [[len(jobs) - 1, b] for b in range((it + 255) // 256)]
+                    ent.append((poff, ops.packed_elems(Mj, Kj, True), (Mj, Kj)))
+                    poff += ops.packed_elems(Mj, Kj, True)
+                self.packs.append((m, ent))
+        if jobs:
+            self.parena = torch.empty(poff, device=dev, dtype=torch.float32)
+            self.jobs = torch.tensor(jobs, dtype=torch.int64).to(dev)
+            self.jblks, self.njblk = torch.tensor(jblk, dtype=torch.int32).to(dev), len(jblk)
+            for i, (m, ent) in enumerate(self.packs):
+                vs = []
+                for off_, pe, mk in ent:
+                    v = self.parena[off_:off_ + pe].view(1, pe)
+                    v._bem_mk = mk
+                    vs.append(v)
+                self.packs[i] = (m, vs[0], vs[1])
         self.sig = self._signature()
 
     def sample(self, ctx, step, state=None):
@@ -419,6 +449,12 @@ class BayesBank:
         base = (ctx.rank << 44) | (ctx.epoch << 20) | ctx.counter
         ops.bnn_bank_sample(self, decay(), d_dev, ctx.seed, base, ctx.epoch_dev)
         ctx.counter += len(self.views)
+        if self.packs:
+            ops.pack_pw_weight_jobs(self.jobs, self.jblks, self.njblk, self.parena)
+            for m, fwd, tr in self.packs:
+                m.__dict__["_bank_wp"] = (step, fwd)                                        # gemm_weights of this training forward
+                wv = m.__dict__["_bank_wv"]
+                ag._derived(m).d["T"] = ((ops.WEIGHT_EPOCH[0], (wv.data_ptr(), ops.tensor_version(wv))), tr)   # autograd._pack(m, "T", [w], ...) hits
         for m, kind, wv, ev in self.views:
             if kind == "weight":
                 m._ws, m._eps_w, m._bs, m._eps_b = wv, ev, None, None
@@ -547,6 +583,9 @@ class Conv2dReparameterization(_BayesBase):
     def gemm_weights(self, B):
         if self.deterministic or not ops.USE_X6 or self.training:
             w, b, ns = self._sampled(B)
+            bw = self.__dict__.get("_bank_wp")
+            if self.training and bw is not None and bw[0] is self._sample_owner and not self.deterministic:
+                return bw[1], b                      # packed by the bank's one launch for this forward
             return ops.pack_pw_weight(w.reshape(ns, self.out_channels, self.in_channels).contiguous()), b
         Wp, b, _ = self._sampled(B, (self.out_channels, self.in_channels))
         return Wp, b
@@ -577,6 +616,9 @@ class Linear2dReparameterization(_BayesBase):
     def gemm_weights(self, B):
         if self.deterministic or not ops.USE_X6 or self.training:
             w, b, ns = self._sampled(B)
+            bw = self.__dict__.get("_bank_wp")
+            if self.training and bw is not None and bw[0] is self._sample_owner and not self.deterministic:
+                return bw[1], b
             return ops.pack_pw_weight(w.contiguous()), b
         Wp, b, _ = self._sampled(B, (self.out_features, self.in_features))
         return Wp, b

@@ -65,6 +65,7 @@ SIGNATURES = {
     "bem_pw_gemm_x6_f32": [ctypes.POINTER(PwArgs), P],
     "bem_pack_pw_weight_x6": [P, P, I, I, I, P],
     "bem_pack_pw_weight_x6_strided": [P, P, I, I, I, I64, I64, I64, P],
+    "bem_pack_pw_weight_x6_jobs": [P, P, I, P, P],
     "bem_pw_x6_packed_elems": [I, I],
     "bem_bnn_sample_pack_x6": [P, P, P, P, I, I, I, U64, U64, P, I, P],
     "bem_store_words": [P, P, I, P],

@@ -672,6 +672,10 @@ def bnn_ebank_sample(bank, seed, stream_base):
     check(lib().bem_bnn_ebank_sample_f32(_p(bank.segs), _p(bank.blks), bank.nblk, _p(bank.arena), seed, stream_base, _stream()), "bnn_ebank_sample")
 
 
+def pack_pw_weight_jobs(jobs, blks, nblk, arena):
+    check(lib().bem_pack_pw_weight_x6_jobs(_p(jobs), _p(blks), nblk, _p(arena), _stream()), "pack_pw_weight_x6_jobs")
+
+
 def bnn_bank_kl_(bank, out):
     _chk(out, "out")
     check(lib().bem_bnn_bank_kl_f32(_p(bank.segs), _p(bank.blks), bank.nblk, _p(bank.pm), _p(bank.pr), _p(out), _stream()), "bnn_bank_kl")

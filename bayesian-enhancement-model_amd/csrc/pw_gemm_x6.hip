@@ -626,10 +626,8 @@ __global__ __launch_bounds__(256, 2) void pw_x6_stream_kernel(PwX k) {
 }
 
 // natural (nsets, M, K) f32 -> (nsets, MT, KB, 3, 64) 16-byte vectors of bf16 limbs
-__global__ void pack_x6_kernel(const float* __restrict__ W, u32x4* __restrict__ Wp, int M, int K, int MT, int KB, int64_t total,
-                               int64_t ss, int64_t rs, int64_t cs) {      // element strides of W over (set, row, k): transposed / sliced views pack in place
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
+__device__ __forceinline__ void pack_x6_item(int64_t i, const float* __restrict__ W, u32x4* __restrict__ Wp, int M, int K, int MT, int KB,
+                                             int64_t ss, int64_t rs, int64_t cs) {      // element strides of W over (set, row, k): transposed / sliced views pack in place
     const int lane = (int)(i & 63);
     const int64_t blk = i >> 6;
     const int kb = (int)(blk % KB), mt = (int)((blk / KB) % MT);
@@ -642,6 +640,27 @@ __global__ void pack_x6_kernel(const float* __restrict__ W, u32x4* __restrict__ 
     split8(v, h, m, l);
     u32x4* o = Wp + ((set * MT + mt) * KB + kb) * 3 * 64 + lane;
     o[0] = h; o[64] = m; o[128] = l;
+}
+
+__global__ void pack_x6_kernel(const float* __restrict__ W, u32x4* __restrict__ Wp, int M, int K, int MT, int KB, int64_t total,
+                               int64_t ss, int64_t rs, int64_t cs) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    pack_x6_item(i, W, Wp, M, K, MT, KB, ss, rs, cs);
+}
+
+// Many (M, K) matrices packed by one launch: job = { source pointer, first float of the packed output in `arena` (multiple of 4), int32 M,
+// int32 K, row stride, column stride (elements), work items = ceil(M/32) ceil(K/16) 64 }; blk = { job, first block of 256 work items }.
+// A Stage-I training step re-packs the forward and the transposed operand of every Bayesian 1x1 layer (the weights are new draws each
+// iteration): ~120 launches of a few KiB otherwise.
+struct packjob { const float* src; int64_t out; int32_t M, K; int64_t rs, cs, items, pad0, pad1; };
+static_assert(sizeof(packjob) == 8 * 8, "packjob is eight 64-bit words (bem.modules.BayesBank builds it as an int64 table)");
+
+__global__ __launch_bounds__(256) void pack_x6_jobs_kernel(const packjob* __restrict__ jobs, const int32_t* __restrict__ blks, float* __restrict__ arena) {
+    const packjob jb = jobs[blks[2 * blockIdx.x]];
+    const int64_t i = (int64_t)blks[2 * blockIdx.x + 1] * 256 + threadIdx.x;
+    if (i >= jb.items) return;
+    pack_x6_item(i, jb.src, reinterpret_cast<u32x4*>(arena + jb.out), jb.M, jb.K, (jb.M + 31) / 32, (jb.K + 15) / 16, 0, jb.rs, jb.cs);
 }
 
 // Bayesian weight sets straight into operand order: w[set][row][k] = mu + log1p(exp(rho)) * eps, eps injected or drawn
@@ -769,6 +788,13 @@ extern "C" int bem_pack_pw_weight_x6_strided(const float* W, float* Wp, int nset
     pack_x6_kernel<<<(unsigned)cdiv64(total, 256), 256, 0, (hipStream_t)stream>>>(W, reinterpret_cast<u32x4*>(Wp), M, K, MT, KB, total, set_stride,
                                                                                  row_stride, col_stride);
     return bem_check_launch("pack_pw_weight_x6");
+}
+
+extern "C" int bem_pack_pw_weight_x6_jobs(const void* jobs, const void* blks, int nblk, float* arena, void* stream) {
+    BEM_REQUIRE(jobs && blks && arena && nblk > 0, "pack_pw_weight_x6_jobs: bad arguments");
+    BEM_REQUIRE(((uintptr_t)arena & 15) == 0, "pack_pw_weight_x6_jobs: the arena must be 16-byte aligned");
+    pack_x6_jobs_kernel<<<nblk, 256, 0, (hipStream_t)stream>>>((const packjob*)jobs, (const int32_t*)blks, arena);
+    return bem_check_launch("pack_pw_weight_x6_jobs");
 }
 
 extern "C" int bem_pack_pw_weight_x6(const float* W, float* Wp, int nsets, int M, int K, void* stream) {

@@ -143,6 +143,10 @@ int bem_pack_pw_weight_x6(const float* W, float* Wp, int nsets, int M, int K, vo
  * or a column block of a concatenated weight is packed where it lies, without a contiguous copy. */
 int bem_pack_pw_weight_x6_strided(const float* W, float* Wp, int nsets, int M, int K, int64_t set_stride, int64_t row_stride,
                                   int64_t col_stride, void* stream);
+/* Many matrices packed by one launch.  jobs: njobs x 8 64-bit words {source pointer; first float of the packed output in `arena` (multiple
+ * of 4); int32 M, int32 K; row stride; column stride (elements); work items = ceil(M/32) * ceil(K/16) * 64; 0; 0}; blks: nblk x {int32 job,
+ * int32 first block of 256 work items}.  Each output is what bem_pack_pw_weight_x6_strided writes for that view (one set). */
+int bem_pack_pw_weight_x6_jobs(const void* jobs, const void* blks, int nblk, float* arena, void* stream);
 int64_t bem_pw_x6_packed_elems(int M, int K);
 /* bem_bnn_sample_f32 (below) and bem_pack_pw_weight_x6 in one pass for the weights of a Bayesian 1x1 layer: nsets weight
  * sets w = mu + log1p(exp(rho)) * eps written straight in x6 operand order; eps (nsets, M, K) injected or NULL = the
