@@ -137,6 +137,9 @@ class ConditionGenerator(BaseModel):
         key = (tuple(self.lq.shape), tuple(self.gt.shape), None if self.mask is None else tuple(self.mask.shape))
         graphs = self.__dict__.setdefault("_graphs", {})
         g = graphs.get(key)
+        bank = self.get_bare_model(self.net_g).__dict__.get("_bayes_bank")
+        if isinstance(g, dict) and g["bank_sig"] is not (bank.sig if bank is not None else None):
+            g = None                 # the bank rebuilt its tables (a parameter / gradient / prior buffer moved): the recorded launches point at the old ones
         if g is None:
             graphs[key] = "warm"
             return self._step_body(current_iter, skip, None)
@@ -153,6 +156,8 @@ class ConditionGenerator(BaseModel):
             finally:
                 bt.STEP_STATE[0] = None
                 self.lq, self.gt, self.mask = feed
+            bank = self.get_bare_model(self.net_g).__dict__.get("_bayes_bank")
+            g["bank_sig"] = bank.sig if bank is not None else None
             graphs[key] = g
         for dst, src in ((g["lq"], self.lq), (g["gt"], self.gt), (g["mask"], self.mask)):
             if dst is not None and dst.data_ptr() != src.data_ptr():
