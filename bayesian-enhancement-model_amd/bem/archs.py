@@ -402,8 +402,8 @@ class CrossFusionBlock(nn.Module):
 
     def forward(self, x_src, x_tgt):
         _need_cuda(x_src)
-        if grad_mode(self):
-            raise BemNativeError("CrossFusionBlock: inference only (DecompDualBranch has no training kernels)")
+        if grad_mode(self):                      # training: the transform as its own autograd node, then x_tgt + gate * t
+            return ag.GateAddFn.apply(self.transform(x_src), self.gate, x_tgt)
         t, C = self.transform, self.transform.out_channels
         Wp, b = self._cache.get("gated", [t.weight, t.bias, self.gate], lambda: (
             ops.pack_pw_weight(ops.row_scale(t.weight.detach().reshape(C, C).contiguous(), self.gate.detach().reshape(C).contiguous())),
@@ -425,7 +425,11 @@ class SEBlock(nn.Module):
         return ops.se_gate(x, self.fc[0].weight.detach(), self.fc[2].weight.detach())
 
     def forward(self, x):
-        raise BemNativeError("SEBlock is applied through SpatialAttention.forward(x, chan_scale=se.gate(x)); it has no standalone forward here")
+        """Training form (the scaled tensor is materialised: the backward needs it); inference goes through gate() + SpatialAttention."""
+        _need_cuda(x)
+        if grad_mode(self):
+            return ag.SEBlockFn.apply(x, self.fc[0].weight, self.fc[2].weight)
+        return ops.chan_scale(x.contiguous(), self.gate(x))
 
 
 class SpatialAttention(nn.Module):
@@ -440,14 +444,16 @@ class SpatialAttention(nn.Module):
     def forward(self, x, chan_scale=None):
         _need_cuda(x)
         if grad_mode(self):
-            raise BemNativeError("SpatialAttention: inference only (DecompDualBranch has no training kernels)")
+            if chan_scale is not None:
+                raise BemNativeError("SpatialAttention: the training form takes the SE-scaled tensor (SEBlock.forward), not a gate")
+            return ag.SpatialAttnFn.apply(x, self.conv.weight)
         return ops.spatial_attention(x, self.conv.weight.detach(), chan_scale)
 
 
 class DecompDualBranch(nn.Module):
     """DecompModel_arch.py:101-366: the image's two quaternion maps (4 channels each; the condition half of the 6-channel input is not
     read, :294) through two U-Nets with their own bottlenecks.  State-dict keys follow the reference: branch 1 without suffix, branch 2
-    with the suffix ``2``.  Inference only."""
+    with the suffix ``2``."""
 
     def __init__(self, in_channels=3, out_channels=3, n_feat=40, stage=1, num_blocks=[2, 2, 2], d_state=1, ssm_ratio=1,
                  mlp_ratio=4, mlp_type="gdmlp", use_pixelshuffle=False, drop_path=0.0, use_illu=False, sam=False,
@@ -487,34 +493,46 @@ class DecompDualBranch(nn.Module):
         self.apply(_init_weights)
 
     def forward(self, x, mask=None):
+        """Inference: kernels only.  ``train()`` mode with autograd enabled (image_enhancer_model.py:165-216): the frozen decomposition runs
+        without a graph, the two U-Nets, the cross-fusions, SE / attention blocks and the Hamilton product record bem.autograd nodes."""
         _need_cuda(x)
-        if grad_mode(self):
-            raise BemNativeError("DecompDualBranch: inference only (call eval() or run under torch.no_grad())")
+        train = grad_mode(self)
         with torch.no_grad():
             x = x.contiguous()
             B, _, H, W = x.shape
             qi = self.decomp(x, 0)                                      # (B,8,H,W) = [Q1 | Q2] of the image channels
+        with torch.enable_grad() if train else torch.no_grad():
             feats, skips = [], []
             for bi, s_ in enumerate(("", "2")):
                 f = getattr(self, "first_conv" + s_)(qi, cin_slice=(4 * bi, 4))
                 sk = []
                 for i in range(self.num_levels - 1):
                     f = getattr(self, "encoders" + s_)[i](f)
-                    sk.append(f)
+                    f, s1 = ag.fork(f)                                  # two consumers: the down layer and the decoder's skip
+                    sk.append(s1)
                     f = getattr(self, "down_layers" + s_)[i](f)
                 feats.append(f); skips.append(sk)
-            f2 = self.cross_fusion_12(feats[0], feats[1])               # branch 2 takes from branch 1 first ...
-            f1 = self.cross_fusion_21(f2, feats[0])                     # ... and branch 1 from the fused branch 2 (:311-312)
-            out8 = torch.empty(B, 8, H, W, device=x.device, dtype=x.dtype)
-            for bi, (s_, f) in enumerate((("", f1), ("2", f2))):
+            fa, fb = ag.fork(feats[0])                                  # branch 1's deepest features feed both cross-fusions
+            f2 = self.cross_fusion_12(fa, feats[1])                     # branch 2 takes from branch 1 first ...
+            f2a, f2b = ag.fork(f2)
+            f1 = self.cross_fusion_21(f2a, fb)                          # ... and branch 1 from the fused branch 2 (:311-312)
+            outs = []
+            for bi, (s_, f) in enumerate((("", f1), ("2", f2b))):
                 f = getattr(self, "bottleneck" + s_)(f)
-                f = getattr(self, "spatial_attention" + s_)(f, chan_scale=getattr(self, "bottleneck_se" + s_).gate(f))
+                se, sa = getattr(self, "bottleneck_se" + s_), getattr(self, "spatial_attention" + s_)
+                f = sa(se(f)) if train else sa(f, chan_scale=se.gate(f))
                 for j, dec in enumerate(getattr(self, "decoders" + s_)):
                     f = dec["up"](f)
                     f = dec["fuse"](f, x2=skips[bi][self.num_levels - 2 - j], in_mode=2)
                     f = dec["block"](f)
-                ops.copy_channels(getattr(self, "proj" + s_)(f), out8, 4 * bi)
-            out = ops.hamilton(out8)
+                outs.append(getattr(self, "proj" + s_)(f))
+            if train:
+                out = ag.HamiltonFn.apply(outs[0], outs[1])
+            else:
+                out8 = torch.empty(B, 8, H, W, device=x.device, dtype=x.dtype)
+                ops.copy_channels(outs[0], out8, 0)
+                ops.copy_channels(outs[1], out8, 4)
+                out = ops.hamilton(out8)
         return [x, out]
 
 

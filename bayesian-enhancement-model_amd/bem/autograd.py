@@ -549,3 +549,87 @@ class ScaledSumFn(Function):
     def backward(ctx, g):
         g1 = g.reshape(1).contiguous()
         return g, ops.add(torch.zeros_like(g1), g1, ctx.c).reshape(()), None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# DecompDualBranch's bottleneck blocks in training (basicsr/archs/DecompModel_arch.py:57-99)
+# ------------------------------------------------------------------------------------------------------------------
+class GateAddFn(Function):
+    """x_tgt + gate * t  (CrossFusionBlock after its 1x1 transform, :62-66): dt = gate dy, dx_tgt = dy, dgate[c] += sum dy t."""
+
+    @staticmethod
+    def forward(ctx, t, gate, x_tgt):
+        t, x_tgt = t.contiguous(), x_tgt.contiguous()
+        ctx.save_for_backward(t)
+        ctx.gate = gate
+        return ops.chan_scale(t, gate.detach().reshape(-1).contiguous(), add=x_tgt)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (t,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        g = ctx.gate
+        ops.chan_dot(dy, t, grad_of(g).view(-1))
+        return ops.chan_scale(dy, g.detach().reshape(-1).contiguous()), None, dy
+
+
+class SEBlockFn(Function):
+    """x * sigmoid(W2 relu(W1 mean_hw(x)))  (SEBlock, :68-83)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2):
+        x = x.contiguous()
+        y, mean = ops.se_gate(x, w1.detach(), w2.detach(), want_mean=True)
+        ctx.save_for_backward(x, y, mean)
+        ctx.w = (w1, w2)
+        return ops.chan_scale(x, y)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, y, mean = ctx.saved_tensors
+        w1, w2 = ctx.w
+        dout = dout.contiguous()
+        dy = ops.chan_dot(dout, x)                                                     # (B,C): gradient of the gate
+        dmean = ops.se_gate_bwd(mean, w1.detach(), w2.detach(), y, dy, grad_of(w1), grad_of(w2))
+        return ops.chan_scale(dout, y, add_bc=dmean, add_bc_scale=1.0 / x[0, 0].numel()), None, None
+
+
+class SpatialAttnFn(Function):
+    """x * sigmoid(conv_kxk([mean_c x, max_c x]))  (SpatialAttention, :85-99)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        x = x.contiguous()
+        out, amap = ops.spatial_attention(x, w.detach(), want_map=True)
+        ctx.save_for_backward(x, amap)
+        ctx.w = w
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, amap = ctx.saved_tensors
+        w = ctx.w
+        return ops.spatial_attention_bwd(x, dout.contiguous(), amap, w.detach(), grad_of(w)), None
+
+
+class HamiltonFn(Function):
+    """hamilton_product(p, q)[:, 1:] of two (B,4,H,W) maps at full resolution (DecompModel_arch.py:351-352)."""
+
+    @staticmethod
+    def forward(ctx, p, q):
+        B, _, H, W = p.shape
+        q8 = torch.empty(B, 8, H, W, device=p.device, dtype=p.dtype)
+        ops.copy_channels(p.contiguous(), q8, 0)
+        ops.copy_channels(q.contiguous(), q8, 4)
+        ctx.save_for_backward(q8)
+        return ops.hamilton(q8)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (q8,) = ctx.saved_tensors
+        d = ops.hamilton_bwd(q8, dout.contiguous())
+        B, _, H, W = q8.shape
+        dp, dq = torch.empty(B, 4, H, W, device=d.device, dtype=d.dtype), torch.empty(B, 4, H, W, device=d.device, dtype=d.dtype)
+        ops.copy_channels(d, dp, 0, src_c0=0, C=4)
+        ops.copy_channels(d, dq, 0, src_c0=4, C=4)
+        return dp, dq

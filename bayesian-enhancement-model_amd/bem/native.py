@@ -77,6 +77,11 @@ SIGNATURES = {
     "bem_row_scale_f32": [P, P, P, I, I, P],
     "bem_se_gate_f32": [P, P, P, P, I, I, I, P],
     "bem_spatial_attention_f32": [P, P, P, P, P, I, I, I, I, I, P],
+    "bem_hamilton_bwd_f32": [P, P, P, I, I, I, P],
+    "bem_chan_scale_f32": [P, P, I64, P, P, F, P, I, I, I64, P],
+    "bem_chan_dot_f32": [P, P, P, I, I, I64, I, P],
+    "bem_se_gate_bwd_f32": [P, P, P, P, P, P, P, P, I, I, I, P],
+    "bem_spatial_attention_bwd_f32": [P, P, P, P, P, P, P, I, I, I, I, I, P],
     "bem_bnn_prior_ema_f32": [P, P, P, P, F, P, I64, P],
     "bem_bnn_kl_f32": [P, P, P, P, I64, P, P],
     "bem_bnn_kl_bwd_f32": [P, P, P, P, I64, P, P, P, P],

@@ -526,6 +526,17 @@ def hamilton(q):
     return out
 
 
+def hamilton_bwd(q8, dout):
+    """Backward of hamilton(): q8 (B,8,H,W), dout (B,3,H,W) -> (B,8,H,W) = [dp | dq]."""
+    _chk(q8, "q8"); _chk(dout, "dout")
+    B, C, H, W = q8.shape
+    if C != 8 or tuple(dout.shape) != (B, 3, H, W):
+        raise ValueError("hamilton_bwd: shapes")
+    d = torch.empty_like(q8)
+    check(lib().bem_hamilton_bwd_f32(_p(q8), _p(dout), _p(d), B, H, W, _stream()), "hamilton_bwd")
+    return d
+
+
 def hamilton_full(q1, q2):
     """QD/quaternion.py hamilton_product: (B,4,H,W) x (B,4,H,W) -> (B,4,H,W) = [real, i, j, k]."""
     _chk(q1, "q1"); _chk(q2, "q2")
@@ -846,7 +857,7 @@ def row_scale(w, scale):
     return out
 
 
-def se_gate(x, w1, w2):
+def se_gate(x, w1, w2, want_mean=False):
     """SEBlock's per-channel gate (B,C) = sigmoid(w2 relu(w1 mean_hw(x)))."""
     _chk(x, "x"); _chk(w1, "w1"); _chk(w2, "w2")
     B, C = x.shape[0], x.shape[1]
@@ -856,11 +867,11 @@ def se_gate(x, w1, w2):
     mean = plane_mean(x)
     y = torch.empty(B, C, device=x.device, dtype=x.dtype)
     check(lib().bem_se_gate_f32(_p(mean), _p(w1), _p(w2), _p(y), B, C, Cr, _stream()), "se_gate")
-    return y
+    return (y, mean) if want_mean else y
 
 
-def spatial_attention(x, w, chan_scale=None):
-    """x * chan_scale * sigmoid(conv_kxk([mean_c, max_c](x * chan_scale))); w (1,2,k,k)."""
+def spatial_attention(x, w, chan_scale=None, want_map=False):
+    """x * chan_scale * sigmoid(conv_kxk([mean_c, max_c](x * chan_scale))); w (1,2,k,k).  want_map: also the (B,2,H,W) map (for the backward)."""
     _chk(x, "x"); _chk(w, "w"); _chk(chan_scale, "chan_scale", optional=True)
     B, C, H, W = x.shape
     k = w.shape[-1]
@@ -869,7 +880,55 @@ def spatial_attention(x, w, chan_scale=None):
     ws = torch.empty(B, 2, H, W, device=x.device, dtype=x.dtype)
     out = torch.empty_like(x)
     check(lib().bem_spatial_attention_f32(_p(x), _p(chan_scale), _p(w), _p(ws), _p(out), B, C, H, W, k, _stream()), "spatial_attention")
+    return (out, ws) if want_map else out
+
+
+def spatial_attention_bwd(x, dout, amap, w, dw):
+    """Backward of spatial_attention(x, w): returns dx; dw (1,2,k,k) accumulated."""
+    for t, n in ((x, "x"), (dout, "dout"), (amap, "map"), (w, "w"), (dw, "dw")):
+        _chk(t, n)
+    B, C, H, W = x.shape
+    dpre = torch.empty(B, H, W, device=x.device, dtype=x.dtype)
+    dx = torch.empty_like(x)
+    check(lib().bem_spatial_attention_bwd_f32(_p(x), _p(dout), _p(amap), _p(w), _p(dpre), _p(dx), _p(dw), B, C, H, W, w.shape[-1], _stream()),
+          "spatial_attention_bwd")
+    return dx
+
+
+def chan_scale(x, scale, add=None, add_bc=None, add_bc_scale=1.0):
+    """scale[(b,) c] * x (+ add) (+ add_bc[b, c] * add_bc_scale); scale (C) or (B, C)."""
+    _chk(x, "x"); _chk(scale, "scale"); _chk(add, "add", optional=True); _chk(add_bc, "add_bc", optional=True)
+    B, C = x.shape[0], x.shape[1]
+    HW = x[0, 0].numel()
+    if scale.numel() not in (C, B * C) or (add is not None and add.shape != x.shape) or (add_bc is not None and add_bc.numel() != B * C):
+        raise ValueError("chan_scale: shapes")
+    out = torch.empty_like(x)
+    check(lib().bem_chan_scale_f32(_p(x), _p(scale), C if (scale.numel() == B * C and scale.dim() > 1) else 0, _p(add), _p(add_bc), float(add_bc_scale), _p(out),
+                                   B, C, HW, _stream()), "chan_scale")
     return out
+
+
+def chan_dot(a, b, out=None):
+    """out is None: (B,C) = sum_p a b per image; out (C): += sum over images and pixels (a parameter's gradient)."""
+    _chk(a, "a"); _chk(b, "b"); _chk(out, "out", optional=True)
+    B, C = a.shape[0], a.shape[1]
+    HW = a[0, 0].numel()
+    if b.shape != a.shape or (out is not None and out.numel() != C):
+        raise ValueError("chan_dot: shapes")
+    per = out is None
+    if per:
+        out = torch.empty(B, C, device=a.device, dtype=a.dtype)
+    check(lib().bem_chan_dot_f32(_p(a), _p(b), _p(out), B, C, HW, int(per), _stream()), "chan_dot")
+    return out
+
+
+def se_gate_bwd(mean, w1, w2, y, dy, dw1, dw2):
+    for t, n in ((mean, "mean"), (w1, "w1"), (w2, "w2"), (y, "y"), (dy, "dy"), (dw1, "dw1"), (dw2, "dw2")):
+        _chk(t, n)
+    B, C = mean.shape
+    dmean = torch.empty_like(mean)
+    check(lib().bem_se_gate_bwd_f32(_p(mean), _p(w1), _p(w2), _p(y), _p(dy), _p(dmean), _p(dw1), _p(dw2), B, C, w1.shape[0], _stream()), "se_gate_bwd")
+    return dmean
 
 
 def cond_postproc(pred, target_mean, noise, samples_per_image, noise_level):

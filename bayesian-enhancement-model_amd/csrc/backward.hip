@@ -586,6 +586,36 @@ extern "C" int bem_l1_loss_f32(const float* pred, const float* gt, float* dpred,
     return bem_check_launch("l1_loss");
 }
 
+namespace {
+// backward of bem_hamilton_f32: q (B,8,HW) = [p | q], dout (B,3,HW) = d(i, j, k parts of p x q)  ->  dq8 (B,8,HW) = [dp | dq]
+__global__ void hamilton_bwd_kernel(const float* __restrict__ q8, const float* __restrict__ dout, float* __restrict__ dq8, int64_t HW, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t pix = i % HW, b = i / HW;
+    const float* s = q8 + b * 8 * HW + pix;
+    const float p[4] = {s[0], s[HW], s[2 * HW], s[3 * HW]}, q[4] = {s[4 * HW], s[5 * HW], s[6 * HW], s[7 * HW]};
+    const float* g = dout + b * 3 * HW + pix;
+    const float gi = g[0], gj = g[HW], gk = g[2 * HW];
+    float* d = dq8 + b * 8 * HW + pix;
+    // i = p0 q1 + p1 q0 + p2 q3 - p3 q2;  j = p0 q2 - p1 q3 + p2 q0 + p3 q1;  k = p0 q3 + p1 q2 - p2 q1 + p3 q0
+    d[0] = gi * q[1] + gj * q[2] + gk * q[3];
+    d[HW] = gi * q[0] - gj * q[3] + gk * q[2];
+    d[2 * HW] = gi * q[3] + gj * q[0] - gk * q[1];
+    d[3 * HW] = -gi * q[2] + gj * q[1] + gk * q[0];
+    d[4 * HW] = gi * p[1] + gj * p[2] + gk * p[3];
+    d[5 * HW] = gi * p[0] + gj * p[3] - gk * p[2];
+    d[6 * HW] = -gi * p[3] + gj * p[0] + gk * p[1];
+    d[7 * HW] = gi * p[2] - gj * p[1] + gk * p[0];
+}
+}  // namespace
+
+extern "C" int bem_hamilton_bwd_f32(const float* q8, const float* dout, float* dq8, int B, int H, int W, void* stream) {
+    BEM_REQUIRE(q8 && dout && dq8 && B > 0 && H > 0 && W > 0, "hamilton_bwd: bad arguments");
+    const int64_t HW = (int64_t)H * W, total = (int64_t)B * HW;
+    hamilton_bwd_kernel<<<GRID1D(total), 256, 0, (hipStream_t)stream>>>(q8, dout, dq8, HW, total);
+    return bem_check_launch("hamilton_bwd");
+}
+
 extern "C" int bem_iwt_hamilton_bwd_f32(const float* q1w, const float* q2w, const float* dout, float* dq1w, float* dq2w, int B, int h, int w,
                                         void* stream) {
     BEM_REQUIRE(q1w && q2w && dout && dq1w && dq2w && B > 0 && h > 0 && w > 0, "iwt_hamilton_bwd: bad arguments");

@@ -276,6 +276,19 @@ int bem_se_gate_f32(const float* mean, const float* w1, const float* w2, float* 
 int bem_spatial_attention_f32(const float* x, const float* chan_scale, const float* w, float* map_ws, float* out, int B, int C, int H, int W,
                               int k, void* stream);
 
+/* Training side of the same blocks (autograd nodes of bem/autograd.py: CrossFusion = PwFn + GateAddFn, SEBlockFn, SpatialAttnFn).
+ * chan_scale: out = scale[b * scale_bstride + c] * x (+ add) (+ add_bc[b][c] * add_bc_scale); scale_bstride = C (per-image factors) or 0
+ * (a parameter).  chan_dot: per_batch ? out (B,C) = sum_p a b : out (C) += sum_{b,p} a b.  se_gate_bwd: backward of bem_se_gate_f32 through
+ * sigmoid / W2 / relu / W1 (dw1, dw2 accumulated, dmean (B,C) written).  spatial_attention_bwd: backward of bem_spatial_attention_f32 with
+ * chan_scale = NULL; map = the (B,2,H,W) workspace its forward filled, dpre_ws (B,H,W) floats, dw (1,2,k,k) accumulated. */
+int bem_chan_scale_f32(const float* x, const float* scale, int64_t scale_bstride, const float* add, const float* add_bc, float add_bc_scale,
+                       float* out, int B, int C, int64_t HW, void* stream);
+int bem_chan_dot_f32(const float* a, const float* b, float* out, int B, int C, int64_t HW, int per_batch, void* stream);
+int bem_se_gate_bwd_f32(const float* mean, const float* w1, const float* w2, const float* y, const float* dy, float* dmean, float* dw1,
+                        float* dw2, int B, int C, int Cr, void* stream);
+int bem_spatial_attention_bwd_f32(const float* x, const float* dout, const float* map, const float* w, float* dpre_ws, float* dx, float* dw,
+                                  int B, int C, int H, int W, int k, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Bayesian sampling + Monte-Carlo loop pieces (basicsr/bayesian/conv.py:106-114, eval.py:199-264).
  * ------------------------------------------------------------------------------------------- */
@@ -368,6 +381,9 @@ int bem_l1_loss_f32(const float* pred, const float* gt, float* dpred, float* los
 /* Backward of bem_iwt_hamilton_f32: dout (B,3,2h,2w) -> dq1w, dq2w (B,16,h,w) (written). */
 int bem_iwt_hamilton_bwd_f32(const float* q1w, const float* q2w, const float* dout, float* dq1w, float* dq2w, int B, int h, int w,
                              void* stream);
+/* Backward of bem_hamilton_f32 (the full-resolution archs: hamilton_product(out_1, out_2)[:, 1:], DecompModel_arch.py:351-352):
+ * q8 (B,8,H,W) = [p | q], dout (B,3,H,W) -> dq8 (B,8,H,W) = [dp | dq]. */
+int bem_hamilton_bwd_f32(const float* q8, const float* dout, float* dq8, int B, int H, int W, void* stream);
 
 /* nn.PixelUnshuffle(2): x (B,C,2H,2W) -> out (B,4C,H,W), out[c*4 + i*2 + j][y][x] = x[c][2y+i][2x+j] (H, W = OUTPUT plane size).
  * Rearranges dL/dout of ConvTranspose2d(k=2,s=2) so that its input / weight gradients are 1x1 GEMMs, and is the inverse of

@@ -440,6 +440,107 @@ def test_image_enhancer_train_step_matches_oracle(dev):
     assert bad <= 0.01 * tot, f"{bad} of {tot} parameter updates differ from the oracle's"
 
 
+def test_dualbranch_blocks_backward_vs_torch_autograd(dev):
+    """The training forms of DecompDualBranch's bottleneck blocks (DecompModel_arch.py:57-99) and of the full-resolution Hamilton product
+    (:351-352): outputs and every gradient (inputs, 1x1 transform, gate, SE weights, 7x7 / 3x3 attention kernel) against torch's autograd
+    through the oracle's restatements on the CPU."""
+    import bem.archs as A
+    from bem import autograd as ag
+    from oracle import bem_oracle as O
+    gen = G(41)
+    B, C, H, W = 3, 32, 9, 7
+
+    def leaf(*shape, scale=1.0):
+        return (torch.randn(*shape, generator=gen) * scale).requires_grad_()
+
+    def run(mod_out, ref_out, dout, pairs, what):
+        close(mod_out, ref_out, 2e-5, 2e-6, what + " forward")
+        mod_out.backward(dout.to(dev))
+        ref_out.backward(dout)
+        for name, got, want in pairs():
+            close(got, want, 2e-4, 2e-6, f"{what} d{name}")
+
+    # cross-fusion: x_tgt + gate * (W x_src + b)
+    cf = A.CrossFusionBlock(C).to(dev).train()
+    with torch.no_grad():
+        cf.gate.add_(0.3 * torch.randn(1, C, 1, 1, generator=gen).to(dev)); cf.transform.bias.add_(0.1 * torch.randn(C, generator=gen).to(dev))
+    sd = {"cf.transform.weight": cf.transform.weight.detach().cpu().clone().requires_grad_(), "cf.transform.bias": cf.transform.bias.detach().cpu().clone().requires_grad_(),
+          "cf.gate": cf.gate.detach().cpu().clone().requires_grad_()}
+    xs, xt = leaf(B, C, H, W), leaf(B, C, H, W)
+    xs_d, xt_d = xs.detach().to(dev).requires_grad_(), xt.detach().to(dev).requires_grad_()
+    for p_ in cf.parameters():
+        p_.grad = None
+    run(cf(xs_d, xt_d), O.cross_fusion_ref(sd, "cf.", xs, xt), torch.randn(B, C, H, W, generator=gen),
+        lambda: [("x_src", xs_d.grad, xs.grad), ("x_tgt", xt_d.grad, xt.grad), ("W", cf.transform.weight.grad, sd["cf.transform.weight"].grad),
+                 ("b", cf.transform.bias.grad, sd["cf.transform.bias"].grad), ("gate", cf.gate.grad, sd["cf.gate"].grad)], "cross-fusion")
+    # SE block
+    se = A.SEBlock(C, reduction=8).to(dev).train()
+    with torch.no_grad():
+        for p_ in se.parameters():
+            p_.add_(0.8 * torch.randn(p_.shape, generator=gen).to(dev))
+    sd = {"se.fc.0.weight": se.fc[0].weight.detach().cpu().clone().requires_grad_(), "se.fc.2.weight": se.fc[2].weight.detach().cpu().clone().requires_grad_()}
+    x = leaf(B, C, H, W)
+    x_d = x.detach().to(dev).requires_grad_()
+    run(se(x_d), O.se_block_ref(sd, "se.", x), torch.randn(B, C, H, W, generator=gen),
+        lambda: [("x", x_d.grad, x.grad), ("W1", se.fc[0].weight.grad, sd["se.fc.0.weight"].grad), ("W2", se.fc[2].weight.grad, sd["se.fc.2.weight"].grad)], "SE")
+    # spatial attention, both kernel sizes
+    for k in (7, 3):
+        sa = A.SpatialAttention(k).to(dev).train()
+        with torch.no_grad():
+            sa.conv.weight.add_(0.5 * torch.randn(sa.conv.weight.shape, generator=gen).to(dev))
+        sd = {"sa.conv.weight": sa.conv.weight.detach().cpu().clone().requires_grad_()}
+        x = leaf(B, C, H, W)
+        x_d = x.detach().to(dev).requires_grad_()
+        run(sa(x_d), O.spatial_attention_ref(sd, "sa.", x), torch.randn(B, C, H, W, generator=gen),
+            lambda: [("x", x_d.grad, x.grad), ("w", sa.conv.weight.grad, sd["sa.conv.weight"].grad)], f"attention {k}x{k}")
+    # Hamilton product of two 4-channel maps, imaginary parts
+    p4, q4 = leaf(B, 4, H, W), leaf(B, 4, H, W)
+    p_d, q_d = p4.detach().to(dev).requires_grad_(), q4.detach().to(dev).requires_grad_()
+    run(ag.HamiltonFn.apply(p_d, q_d), O.hamilton_ref(p4, q4)[:, 1:], torch.randn(B, 3, H, W, generator=gen),
+        lambda: [("p", p_d.grad, p4.grad), ("q", q_d.grad, q4.grad)], "Hamilton")
+
+
+def test_dualbranch_train_step_matches_oracle(dev):
+    """ImageEnhancer.optimize_parameters with DecompDualBranch as the net (Options/DecompDualBranch_*.yml) for two steps against the oracle's
+    restatement of the training step (image_enhancer_model.py:165-216) around dualbranch_ref on the fixture's weights: loss, gradient norm,
+    parameter updates."""
+    from basicsr.models import build_model
+    from oracle import bem_oracle as O
+    g = load_golden("g12_dualbranch")
+    opt = dict(model_type="ImageEnhancer", is_train=True, num_gpu=1, dist=False, condition=dict(type="mean", scale_down=16, noise_level=0.0),
+               network_g=dict(type="DecompDualBranch", in_channels=6, out_channels=3, n_feat=16, d_state=[1, 1, 1], ssm_ratio=1, mlp_ratio=4,
+                              mlp_type="gdmlp", use_pixelshuffle=True, drop_path=0.0, sam=False, stage=1, num_blocks=[1, 1, 1], decomp_model="model4"),
+               path=dict(pretrain_network_g=None, strict_load_g=True, resume_state=None),
+               train=dict(total_iter=10, warmup_iter=-1, max_grad_norm=1, use_amp=False,
+                          scheduler=dict(type="CosineAnnealingRestartCyclicLR", periods=[6, 4], restart_weights=[1, 1], eta_mins=[0.0002, 0.000001]),
+                          optim_g=dict(type="AdamW", lr=2e-4, weight_decay=1e-4, betas=[0.9, 0.999]),
+                          pixel_opt=dict(type="L1Loss", loss_weight=1, reduction="mean")))
+    x = torch.as_tensor(g["x"])
+    lq = x[:, :3].contiguous()
+    gen = G(34)
+    gt = (3.5 * lq + 0.05 * torch.randn(lq.shape, generator=gen)).clamp(0, 1)
+    gt_down = F.interpolate(gt, scale_factor=1 / 16, mode="bilinear") + 0.1 * torch.randn(1, 3, 2, 2, generator=gen)
+    sd0 = {k: torch.as_tensor(v) for k, v in g["sd"].items()}
+    sd = {**sd0, **qd_state_dict("model4")}
+    ref = O.train_step_ref(sd, lq, gt, gt_down, steps=2, lr=2e-4, weight_decay=1e-4, max_grad_norm=1.0, stage2=O.dualbranch_ref)
+    model = build_model(opt)
+    model.net_g.load_state_dict(sd0, strict=False)
+    for it in range(2):
+        model.feed_train_data(dict(lq=lq, gt=gt, gt_down=gt_down))
+        tn = model.optimize_parameters(it + 1)
+        assert abs(float(model.log_dict["l_pix"]) - ref["loss"][it]) < 3e-6, (it, float(model.log_dict["l_pix"]), ref["loss"][it])
+        assert abs(float(tn) - ref["grad_norm"][it]) < 5e-4 * ref["grad_norm"][it], (it, float(tn), ref["grad_norm"][it])
+    named = dict(model.net_g.named_parameters())
+    assert set(ref["params"]) == {k for k in named if not k.startswith("decomp.")}
+    bad = tot = 0
+    for k, v in ref["params"].items():
+        u_ref, u_dev = (v - sd[k]).double(), (named[k].detach().cpu() - sd[k]).double()
+        assert float((u_dev - u_ref).abs().max()) <= 2 * 2 * 2e-4 * 1.05, k
+        bad += int(((u_dev - u_ref).abs() > 0.05 * u_ref.abs() + 2e-6).sum())
+        tot += v.numel()
+    assert bad <= 0.01 * tot, f"{bad} of {tot} parameter updates differ from the oracle's"
+
+
 def test_checkpoint_resume_continues_the_run(dev, tmp_path):
     """save (net_g_<iter>.pth + <iter>.state) after two steps, build a fresh ImageEnhancer through the resume path (load_resume_state
     -> check_resume -> pretrain path, resume_training) and take two more steps: same learning rates and, to the noise of the
@@ -655,7 +756,7 @@ def _run_driver(root, yml, extra, total, auto_resume=False):
     return model, info
 
 
-@pytest.mark.parametrize("yml,first,total", [("DecompDualBranch2DDWavelet_4.yml", 3, 6), ("CG_UNet_LOLv1.yml", 6, 8)])
+@pytest.mark.parametrize("yml,first,total", [("DecompDualBranch2DDWavelet_4.yml", 3, 6), ("CG_UNet_LOLv1.yml", 6, 8), ("DecompDualBranch_4.yml", 3, 6)])
 def test_training_driver_save_resume_reproduces_the_run(dev, tmp_path, yml, first, total):
     """basicsr/train.py:97-262 over the tensor dataset shim: run A trains `total` iterations without a break; run B stops after `first`
     (checkpoints every 3 iterations), is started again with --auto_resume (train.py:74-94: newest .state, resume_training, the loader
