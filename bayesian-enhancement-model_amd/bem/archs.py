@@ -311,27 +311,36 @@ class _DualBranchFullRes(nn.Module):
         self.apply(_init_weights)
 
     def _dual_unet(self, q1, q2):
-        """q1, q2 (B,Cin,H,W) -> Hamilton(Q1_out, Q2_out)[1:]  (B,3,H,W)."""
-        feats, skips = {}, {}
-        for br, q in (("Q1", q1), ("Q2", q2)):
-            f = getattr(self, f"first_conv_{br}")(q)
-            sk = []
-            for i in range(self.num_levels - 1):
-                f = getattr(self, f"encoders_{br}")[i](f)
-                sk.append(f)
-                f = getattr(self, f"down_layers_{br}")[i](f)
-            feats[br], skips[br] = f, sk
-        fused = self.bottleneck_block(self.bottleneck_fuse(feats["Q1"], x2=feats["Q2"], in_mode=2))
-        B, _, H, W = q1.shape
-        out8 = torch.empty(B, 8, H, W, device=q1.device, dtype=q1.dtype)
-        for bi, br in enumerate(("Q1", "Q2")):
-            f = getattr(self, f"bottleneck_to_{br}")(fused)
-            for j, dec in enumerate(getattr(self, f"decoders_{br}")):
-                f = dec["up"](f)
-                f = dec["fuse"](f, x2=skips[br][self.num_levels - 2 - j], in_mode=2)
-                f = dec["block"](f)
-            ops.copy_channels(getattr(self, f"proj_{br}")(f), out8, 4 * bi)
-        return ops.hamilton(out8)
+        """q1, q2 (B,Cin,H,W) -> Hamilton(Q1_out, Q2_out)[1:]  (B,3,H,W): kernels only in inference, bem.autograd nodes in train() mode with
+        autograd on (q1, q2 come from the frozen decomposition and carry no graph)."""
+        train = grad_mode(self)
+        with torch.enable_grad() if train else torch.no_grad():
+            feats, skips = {}, {}
+            for br, q in (("Q1", q1), ("Q2", q2)):
+                f = getattr(self, f"first_conv_{br}")(q)
+                sk = []
+                for i in range(self.num_levels - 1):
+                    f = getattr(self, f"encoders_{br}")[i](f)
+                    f, s1 = ag.fork(f)
+                    sk.append(s1)
+                    f = getattr(self, f"down_layers_{br}")[i](f)
+                feats[br], skips[br] = f, sk
+            fused = self.bottleneck_block(self.bottleneck_fuse(feats["Q1"], x2=feats["Q2"], in_mode=2))
+            outs = []
+            for br, fz in zip(("Q1", "Q2"), ag.fork(fused)):
+                f = getattr(self, f"bottleneck_to_{br}")(fz)
+                for j, dec in enumerate(getattr(self, f"decoders_{br}")):
+                    f = dec["up"](f)
+                    f = dec["fuse"](f, x2=skips[br][self.num_levels - 2 - j], in_mode=2)
+                    f = dec["block"](f)
+                outs.append(getattr(self, f"proj_{br}")(f))
+            if train:
+                return ag.HamiltonFn.apply(outs[0], outs[1])
+            B, _, H, W = q1.shape
+            out8 = torch.empty(B, 8, H, W, device=q1.device, dtype=q1.dtype)
+            ops.copy_channels(outs[0], out8, 0)
+            ops.copy_channels(outs[1], out8, 4)
+            return ops.hamilton(out8)
 
 
 class DecompDualBranch2DD(_DualBranchFullRes):
@@ -356,8 +365,7 @@ class DecompDualBranch2DD(_DualBranchFullRes):
                 ops.copy_channels(qi, q, 0, src_c0=4 * bi, C=4)
                 ops.copy_channels(qc, q, 4, src_c0=4 * bi, C=4)
                 qs.append(q)
-            out = self._dual_unet(qs[0], qs[1])
-        return [x, out]
+        return [x, self._dual_unet(qs[0], qs[1])]
 
 
 class DecompDualBranch2(_DualBranchFullRes):
@@ -383,8 +391,7 @@ class DecompDualBranch2(_DualBranchFullRes):
                 ops.copy_channels(qi, q, 0, src_c0=4 * bi, C=4)
                 ops.add_channels(x, q, 0, src_c0=3, C=3)               # + [cond, 0]
                 qs.append(q)
-            out = self._dual_unet(qs[0], qs[1])
-        return [x[:, 0:3], out]
+        return [x[:, 0:3], self._dual_unet(qs[0], qs[1])]
 
 
 # ------------------------------------------------------------------------------------------------
@@ -581,15 +588,24 @@ class DecompSingleBranch(nn.Module):
             fea = torch.empty(B, 11, H, W, device=x.device, dtype=x.dtype)
             ops.copy_channels(q, fea, 0)
             ops.copy_channels(x, fea, 8, src_c0=3, C=3)
-            out = ops.hamilton(self._unet(fea))
-        return [x, out]
+        return [x, self._run(fea)]
+
+    def _run(self, fea):
+        """The U-Net + Hamilton product on the assembled input: kernels only in inference, bem.autograd nodes in train() mode with autograd on
+        (the frozen decomposition that produced ``fea`` never records)."""
+        if grad_mode(self):
+            with torch.enable_grad():
+                return ag.Hamilton8Fn.apply(self._unet(fea))
+        with torch.no_grad():
+            return ops.hamilton(self._unet(fea))
 
     def _unet(self, fea):
         f = self.first_conv(fea)
         sk = []
         for i in range(self.num_levels - 1):
             f = self.encoders[i](f)
-            sk.append(f)
+            f, s1 = ag.fork(f)                                       # two consumers (down layer, decoder skip); a no-op without a graph
+            sk.append(s1)
             f = self.down_layers[i](f)
         f = self.bottleneck(f)
         for j, dec in enumerate(self.decoders):
@@ -621,8 +637,7 @@ class DecompSingleBranchDD(DecompSingleBranch):
             fea = torch.empty(B, 16, H, W, device=x.device, dtype=x.dtype)
             ops.copy_channels(self.decomp(x, 0), fea, 0)
             ops.copy_channels(self.decomp(x, 3), fea, 8)
-            out = ops.hamilton(self._unet(fea))
-        return [x, out]
+        return [x, self._run(fea)]
 
 
 # ------------------------------------------------------------------------------------------------

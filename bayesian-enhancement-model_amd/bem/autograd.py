@@ -633,3 +633,18 @@ class HamiltonFn(Function):
         ops.copy_channels(d, dp, 0, src_c0=0, C=4)
         ops.copy_channels(d, dq, 0, src_c0=4, C=4)
         return dp, dq
+
+
+class Hamilton8Fn(Function):
+    """The same on one (B,8,H,W) tensor [p | q] (DecompSingleBranch_arch.py:229-231: the single U-Net's 8 output channels)."""
+
+    @staticmethod
+    def forward(ctx, q8):
+        q8 = q8.contiguous()
+        ctx.save_for_backward(q8)
+        return ops.hamilton(q8)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (q8,) = ctx.saved_tensors
+        return ops.hamilton_bwd(q8, dout.contiguous())

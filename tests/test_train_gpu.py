@@ -541,6 +541,49 @@ def test_dualbranch_train_step_matches_oracle(dev):
     assert bad <= 0.01 * tot, f"{bad} of {tot} parameter updates differ from the oracle's"
 
 
+@pytest.mark.parametrize("tag,arch,dm,ref", [("g9_dualdd", "DecompDualBranch2DD", "model4", "dualbranch2dd_ref"), ("g9_dual2", "DecompDualBranch2", "model1", "dualbranch2_ref"),
+                                             ("g9_singledd", "DecompSingleBranchDD", "model1", "singlebranchdd_ref"), ("g6_single", "DecompSingleBranch", "model1", "singlebranch_ref")])
+def test_sibling_archs_train_step_matches_oracle(dev, tag, arch, dm, ref):
+    """The other Stage-II archs of the 14 Decomp*.yml in training: two ImageEnhancer.optimize_parameters steps
+    (full-resolution U-Nets, Hamilton product as an autograd node) against the oracle's training step around that arch's restatement, on the
+    weights of the arch's fixture."""
+    from basicsr.models import build_model
+    from oracle import bem_oracle as O
+    g = load_golden(tag)
+    sd0 = {k: torch.as_tensor(v) for k, v in g["sd"].items()}
+    n_feat, nb = (16, [2, 1, 1]) if tag == "g6_single" else (8, [1, 1, 1])             # the widths the fixtures were recorded at (tests/golden/make_golden.py)
+    opt = dict(model_type="ImageEnhancer", is_train=True, num_gpu=1, dist=False, condition=dict(type="mean", scale_down=16, noise_level=0.0),
+               network_g=dict(type=arch, in_channels=6, out_channels=3, n_feat=n_feat, d_state=[1, 1, 1], ssm_ratio=1, mlp_ratio=4,
+                              mlp_type="gdmlp", use_pixelshuffle=True, drop_path=0.0, sam=False, stage=1, num_blocks=nb, decomp_model=dm),
+               path=dict(pretrain_network_g=None, strict_load_g=True, resume_state=None),
+               train=dict(total_iter=10, warmup_iter=-1, max_grad_norm=1, use_amp=False,
+                          scheduler=dict(type="CosineAnnealingRestartCyclicLR", periods=[6, 4], restart_weights=[1, 1], eta_mins=[0.0002, 0.000001]),
+                          optim_g=dict(type="AdamW", lr=2e-4, weight_decay=1e-4, betas=[0.9, 0.999]),
+                          pixel_opt=dict(type="L1Loss", loss_weight=1, reduction="mean")))
+    lq = torch.as_tensor(g["x"])[:, :3].contiguous()
+    h, w = lq.shape[-2:]
+    gen = G(35)
+    gt = (3.5 * lq + 0.05 * torch.randn(lq.shape, generator=gen)).clamp(0, 1)
+    gt_down = F.interpolate(gt, scale_factor=1 / 16, mode="bilinear") + 0.1 * torch.randn(1, 3, h // 16, w // 16, generator=gen)
+    sd = {**sd0, **qd_state_dict(dm)}
+    r = O.train_step_ref(sd, lq, gt, gt_down, steps=2, lr=2e-4, weight_decay=1e-4, max_grad_norm=1.0, stage2=getattr(O, ref))
+    model = build_model(opt)
+    model.net_g.load_state_dict(sd0, strict=False)
+    for it in range(2):
+        model.feed_train_data(dict(lq=lq, gt=gt, gt_down=gt_down))
+        tn = model.optimize_parameters(it + 1)
+        assert abs(float(model.log_dict["l_pix"]) - r["loss"][it]) < 3e-6, (it, float(model.log_dict["l_pix"]), r["loss"][it])
+        assert abs(float(tn) - r["grad_norm"][it]) < 5e-4 * r["grad_norm"][it], (it, float(tn), r["grad_norm"][it])
+    named = dict(model.net_g.named_parameters())
+    bad = tot = 0
+    for k, v in r["params"].items():
+        u_ref, u_dev = (v - sd[k]).double(), (named[k].detach().cpu() - sd[k]).double()
+        assert float((u_dev - u_ref).abs().max()) <= 2 * 2 * 2e-4 * 1.05, k
+        bad += int(((u_dev - u_ref).abs() > 0.05 * u_ref.abs() + 2e-6).sum())
+        tot += v.numel()
+    assert bad <= 0.01 * tot, f"{bad} of {tot} parameter updates differ from the oracle's"
+
+
 def test_checkpoint_resume_continues_the_run(dev, tmp_path):
     """save (net_g_<iter>.pth + <iter>.state) after two steps, build a fresh ImageEnhancer through the resume path (load_resume_state
     -> check_resume -> pretrain path, resume_training) and take two more steps: same learning rates and, to the noise of the
